@@ -1,0 +1,84 @@
+"""Oracle: FiLM MLP + band-split CNN + attention pooling, eval mode (CPU, fp32).
+
+Functional restatement of reference src/model.py:70-542 driven directly by a
+reference-format `state_dict` (keys as produced by MixingStyleEncoder.state_dict()).
+Dropout layers are identity (eval); BatchNorm uses running statistics.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import mel as omel
+
+
+def n_subbands(n_mels: int, split_size: int, overlap: int) -> int:
+    """model.py:257-261"""
+    n, i = 0, 0
+    while overlap * i <= n_mels - split_size:
+        n += 1
+        i += 1
+    return n
+
+
+def film_params(sd, feats: torch.Tensor) -> torch.Tensor:
+    """model.py:410-464 -> flat (B, n_sub*192); per band [g1(32) b1(32) g2(64) b2(64)]."""
+    p = "film_encoder."
+    h = F.relu(F.linear(feats, sd[p + "feature_mlp.0.weight"], sd[p + "feature_mlp.0.bias"]))
+    h = F.relu(F.linear(h, sd[p + "feature_mlp.3.weight"], sd[p + "feature_mlp.3.bias"]))
+    return F.linear(h, sd[p + "film_head.weight"], sd[p + "film_head.bias"])
+
+
+def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int,
+                taps=None) -> torch.Tensor:
+    """model.py:127-157 for sub-band i.  x (B, 8, split, F) -> (B, 64, H', W')."""
+    p = f"audio_encoder.subnet_cnns.{i}."
+    g1, b1, g2, b2 = torch.split(film[:, i * 192:(i + 1) * 192], [32, 32, 64, 64], dim=1)
+    sub = max(1, split_size // 10)
+
+    def block(x, conv, bn, g, b, pool):
+        x = F.conv2d(x, sd[p + conv + ".weight"], sd[p + conv + ".bias"], padding=3)
+        x = F.batch_norm(x, sd[p + bn + ".running_mean"], sd[p + bn + ".running_var"],
+                         sd[p + bn + ".weight"], sd[p + bn + ".bias"], training=False, eps=1e-5)
+        x = g[:, :, None, None] * x + b[:, :, None, None]
+        return F.max_pool2d(F.relu(x), pool)
+
+    y1 = block(x, "conv1", "bn1", g1, b1, (sub, 5))
+    y2 = block(y1, "conv2", "bn2", g2, b2, (4, 4))
+    if taps is not None:
+        taps[f"pool1_{i}"] = y1
+        taps[f"pool2_{i}"] = y2
+    return y2
+
+
+def attention_pool(sd, x: torch.Tensor) -> torch.Tensor:
+    """model.py:187-211.  x (B, C, T') -> (B, embed)."""
+    p = "audio_encoder.attention_pooling."
+    xt = x.transpose(1, 2)
+    s = F.linear(torch.tanh(F.linear(xt, sd[p + "attention.0.weight"], sd[p + "attention.0.bias"])),
+                 sd[p + "attention.2.weight"], sd[p + "attention.2.bias"])
+    w = torch.softmax(s, dim=1)
+    pooled = (xt * w).sum(dim=1)
+    return F.relu(F.linear(pooled, sd[p + "projection.0.weight"], sd[p + "projection.0.bias"]))
+
+
+def encoder_from_logmel(sd, lm: torch.Tensor, feats: torch.Tensor, split_size=20, overlap=10,
+                        taps=None) -> torch.Tensor:
+    """log-mel (B, 8, M, F), features (B, Fd) -> embeddings (B, E).  model.py:290-382,508-542."""
+    film = film_params(sd, feats)
+    nsub = n_subbands(lm.shape[2], split_size, overlap)
+    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps)
+            for i in range(nsub)]
+    cat = torch.cat(outs, dim=1)  # (B, nsub*64, H', W')
+    flat = cat.reshape(cat.shape[0], cat.shape[1] * cat.shape[2], cat.shape[3])
+    if taps is not None:
+        taps["film"] = film
+        taps["pool_in"] = flat
+    return attention_pool(sd, flat)
+
+
+def encoder_forward(sd, stems: torch.Tensor, feats: torch.Tensor, sample_rate=44100, n_fft=1024,
+                    hop=256, n_mels=128, split_size=20, overlap=10, taps=None) -> torch.Tensor:
+    """stems (B, 8, T) -> embeddings; mel front end + encoder_from_logmel."""
+    lm = omel.logmel(stems, sample_rate, n_fft, hop, n_mels)
+    if taps is not None:
+        taps["logmel"] = lm
+    return encoder_from_logmel(sd, lm, feats, split_size, overlap, taps)

@@ -1,0 +1,129 @@
+"""Shared seeded input builders for oracle / golden / GPU parity tests (data only, no reference code)."""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mst_amd.synth import synth_clip  # noqa: E402
+
+STEMS = ("vocals", "bass", "drums", "other")
+
+CFG_DEFAULT = dict(sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128, split_size=20, overlap=10,
+                   embed_dim=768)
+CFG_BASELINE_SH = dict(sample_rate=44100, n_fft=2048, hop_length=512, n_mels=80, split_size=16, overlap=8,
+                       embed_dim=512)  # reference scripts/train_baseline.sh:41-48
+
+
+def _g(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+def feature_case(name: str, T: int = 44100) -> torch.Tensor:
+    """(8, T) fp32 stems for a named edge case."""
+    if name == "synth":
+        return synth_clip(0, T)
+    if name == "synth1":
+        return synth_clip(1, T)
+    if name == "white":          # SURVEY A.5 sanity vector
+        return 0.1 * torch.randn(8, T, generator=_g(7))
+    if name == "silent_vocals":  # crest = ILD = -100, corr = 0, tilt = 0, flatness = 1
+        x = 0.1 * torch.randn(8, T, generator=_g(8))
+        x[0:2] = 0.0
+        return x
+    if name == "mono":           # every stem L == R: MSR = 0, corr ~ 1
+        x = 0.1 * torch.randn(8, T, generator=_g(9))
+        x[1::2] = x[0::2]
+        return x
+    if name == "dc":             # DC offsets exercise the centred correlation
+        x = 0.05 * torch.randn(8, T, generator=_g(10))
+        return x + torch.tensor([0.3, -0.2, 0.1, 0.1, 0.0, 0.5, -0.4, 0.25])[:, None]
+    if name == "clipped":        # full-scale saturation
+        return (1.5 * torch.randn(8, T, generator=_g(11))).clamp_(-1.0, 1.0)
+    if name == "short_padded":   # clip shorter than clip_samples, zero-padded tail (data.py:283-287)
+        x = synth_clip(3, T)
+        x[:, int(0.4 * T):] = 0.0
+        return x
+    if name == "all_silent":
+        return torch.zeros(8, T)
+    if name == "one_sided":      # R silent in every stem: ILD=+100 clamp, MSR = 1
+        x = 0.1 * torch.randn(8, T, generator=_g(12))
+        x[1::2] = 0.0
+        return x
+    raise KeyError(name)
+
+
+FEATURE_CASES = ("synth", "white", "silent_vocals", "mono", "dc", "clipped", "short_padded",
+                 "all_silent", "one_sided")
+
+
+def n_subbands(n_mels, split_size, overlap):
+    return len(range(0, n_mels - split_size + 1, overlap))
+
+
+def state_dict_shapes(cfg, feature_dim=64):
+    ns = n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    sub = max(1, cfg["split_size"] // 10)
+    freq_dim = (cfg["split_size"] // sub) // 4
+    C = 64 * ns * freq_dim
+    E = cfg["embed_dim"]
+    shapes = {}
+    for i in range(ns):
+        p = f"audio_encoder.subnet_cnns.{i}."
+        for conv, bn, co, ci in (("conv1", "bn1", 32, 8), ("conv2", "bn2", 64, 32)):
+            shapes[p + conv + ".weight"] = (co, ci, 7, 7)
+            shapes[p + conv + ".bias"] = (co,)
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                shapes[p + bn + "." + k] = (co,)
+            shapes[p + bn + ".num_batches_tracked"] = ()
+    a = "audio_encoder.attention_pooling."
+    shapes[a + "attention.0.weight"] = (256, C)
+    shapes[a + "attention.0.bias"] = (256,)
+    shapes[a + "attention.2.weight"] = (1, 256)
+    shapes[a + "attention.2.bias"] = (1,)
+    shapes[a + "projection.0.weight"] = (E, C)
+    shapes[a + "projection.0.bias"] = (E,)
+    f = "film_encoder."
+    shapes[f + "feature_mlp.0.weight"] = (256, feature_dim)
+    shapes[f + "feature_mlp.0.bias"] = (256,)
+    shapes[f + "feature_mlp.3.weight"] = (256, 256)
+    shapes[f + "feature_mlp.3.bias"] = (256,)
+    shapes[f + "film_head.weight"] = (ns * 192, 256)
+    shapes[f + "film_head.bias"] = (ns * 192,)
+    return shapes
+
+
+def make_state_dict(cfg, seed=42, feature_dim=64):
+    """Deterministic reference-format state_dict (trained-looking: non-trivial BN stats, FiLM gamma ~ 1)."""
+    g = _g(seed)
+    sd = {}
+    for k, shp in state_dict_shapes(cfg, feature_dim).items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(100, dtype=torch.long)
+        elif k.endswith("running_var") or (".bn" in k and k.endswith(".weight")):
+            sd[k] = 0.5 + torch.rand(shp, generator=g)
+        elif k.endswith("running_mean") or (".bn" in k and k.endswith(".bias")):
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".weight"):
+            fan_in = math.prod(shp[1:])
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * 0.05
+    # FiLM gammas around 1 so activations stay O(1) through both conv blocks
+    ns = n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    b = sd["film_encoder.film_head.bias"]
+    for i in range(ns):
+        b[i * 192:i * 192 + 32] += 1.0
+        b[i * 192 + 64:i * 192 + 128] += 1.0
+    return sd
+
+
+def checksum(x: torch.Tensor):
+    x = x.double()
+    return [float(x.sum()), float((x * x).sum())]

@@ -1,0 +1,178 @@
+"""Pin the CPU oracle against golden vectors produced by the reference's own code
+(tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import augment as oaug
+from oracle import encoder as oenc
+from oracle import features as ofeat
+from oracle import loss as oloss
+from oracle import mel as omel
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_fbanks_bit_exact():
+    g = load("fbanks.npz")
+    for n_fft, n_mels in ((1024, 128), (1024, 256), (2048, 80)):
+        fb = omel.htk_fbank(44100, n_fft, n_mels).numpy()
+        assert np.array_equal(fb, g[f"fb_{n_fft}_{n_mels}"])
+        assert np.array_equal(omel.hann_periodic(n_fft).numpy(), g[f"win_{n_fft}"])
+    fb = g["fb_1024_128"]
+    assert (fb != 0).sum() == 1008 and (fb != 0).sum(1).max() <= 2 and not fb[:, 0].any()
+
+
+@pytest.mark.parametrize("name", cases.FEATURE_CASES)
+def test_features_edge_cases(name):
+    g = load("features.npz")
+    x = cases.feature_case(name, 44100)
+    close(cases.checksum(x), g[f"{name}.in_checksum"], rtol=1e-12, atol=0)
+    f = ofeat.extract_all_features(x[None])[0].numpy()
+    assert f.shape == (64,)
+    close(f, g[f"{name}.features"], rtol=1e-4, atol=2e-5)
+
+
+def test_features_known_values():
+    """Expected edge-case values listed in SURVEY 8c(iii)."""
+    g = load("features.npz")
+    f = g["silent_vocals.features"]
+    v = f[49:64]  # vocals: dyn(6) rel(1) spec(5) stereo(3)
+    assert v[0] == 0 and v[1] == 0 and v[2] == -100 and v[3] == -100      # rms, crest
+    assert v[10] == 0 and abs(v[11] - 1.0) < 1e-5                          # tilt, flatness
+    assert v[12] == -100 and v[13] == 0                                    # ILD, corr
+    m = g["mono.features"]
+    assert abs(m[12]) < 1e-5 and abs(m[13] - 1.0) < 1e-5 and abs(m[14]) < 1e-9  # bass ILD 0, corr 1, MSR 0
+    w = g["white.features"]
+    assert abs(w[0] - 0.1) < 2e-3 and abs(w[4] + 20.69) < 0.05 and abs(w[6] + 6.02) < 0.05
+
+
+def test_features_full_size_cfg2_detailed_odd():
+    g = load("features.npz")
+    for c in (0, 1):
+        x = cases.synth_clip(c, 441000)
+        close(cases.checksum(x), g[f"synth10s_{c}.in_checksum"], rtol=1e-12, atol=0)
+        close(ofeat.extract_all_features(x[None])[0].numpy(), g[f"synth10s_{c}.features"], atol=2e-5)
+    x = cases.feature_case("synth1", 66150)
+    close(ofeat.extract_all_features(x[None], 44100, 2048, 512, 80)[0].numpy(), g["cfg2.features"], atol=2e-5)
+    x = cases.feature_case("synth", 44100)
+    f = ofeat.extract_all_features(x[None], detailed=True, n_bins=32)[0].numpy()
+    assert f.shape == (180,)
+    close(f, g["detailed.features"], atol=2e-5)
+    x = cases.feature_case("synth1", 30001)
+    close(ofeat.extract_all_features(x[None])[0].numpy(), g["odd.features"], atol=2e-5)
+
+
+def test_logmel():
+    g = load("logmel.npz")
+    for name, T in (("synth", 4096), ("synth1", 22050), ("one_sided", 8192)):
+        x = cases.feature_case(name, T)[None]
+        lm = omel.logmel(x).numpy()
+        assert lm.shape == (1, 8, 128, 1 + T // 256)
+        close(lm, g[f"{name}_{T}.logmel"], rtol=1e-5, atol=1e-5)
+    lm = omel.logmel(cases.synth_clip(0, 441000)[None])[0]
+    assert lm.shape == (8, 128, 1723)
+    close(lm.flatten()[torch.from_numpy(g["synth10s_0.logmel_idx"])].numpy(), g["synth10s_0.logmel_samples"],
+          rtol=1e-5, atol=1e-5)
+    close(lm.double().sum(-1).numpy(), g["synth10s_0.logmel_rowsum"], rtol=1e-6, atol=1e-3)
+    lm2 = omel.logmel(cases.feature_case("synth1", 66150)[None], 44100, 2048, 512, 80).numpy()
+    close(lm2, g["cfg2.logmel"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,cfg,T", [("default", cases.CFG_DEFAULT, 441000),
+                                        ("cfg2", cases.CFG_BASELINE_SH, 441000),
+                                        ("default_short", cases.CFG_DEFAULT, 66150)])
+def test_encoder(tag, cfg, T):
+    g = load("encoder.npz")
+    sd = cases.make_state_dict(cfg, seed=42)
+    x = torch.stack([cases.synth_clip(c, T) for c in (0, 1)], 0)
+    close(cases.checksum(x), g[f"{tag}.in_checksum"], rtol=1e-12, atol=0)
+    feats = ofeat.extract_all_features(x, cfg["sample_rate"], cfg["n_fft"], cfg["hop_length"], cfg["n_mels"])
+    close(feats.numpy(), g[f"{tag}.features"], atol=2e-5)
+    taps = {}
+    emb = oenc.encoder_forward(sd, x, torch.from_numpy(g[f"{tag}.features"]), cfg["sample_rate"], cfg["n_fft"],
+                               cfg["hop_length"], cfg["n_mels"], cfg["split_size"], cfg["overlap"], taps)
+    assert tuple(emb.shape) == (2, cfg["embed_dim"])
+    close(taps["film"].numpy(), g[f"{tag}.film"], rtol=1e-5, atol=1e-6)
+    pin = taps["pool_in"]
+    assert tuple(pin.shape) == tuple(g[f"{tag}.pool_in_shape"])
+    close(pin.flatten()[torch.from_numpy(g[f"{tag}.pool_in_idx"])].numpy(), g[f"{tag}.pool_in_samples"],
+          rtol=1e-4, atol=1e-5)
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    for i in (0, ns // 2, ns - 1):
+        p1 = taps[f"pool1_{i}"]
+        assert tuple(p1.shape) == tuple(g[f"{tag}.pool1_{i}_shape"])
+        close(p1.flatten()[torch.from_numpy(g[f"{tag}.pool1_{i}_idx"])].numpy(), g[f"{tag}.pool1_{i}_samples"],
+              rtol=1e-4, atol=1e-5)
+    scale = np.abs(g[f"{tag}.embedding"]).max()
+    close(emb.numpy(), g[f"{tag}.embedding"], rtol=1e-4, atol=1e-5 * scale)
+
+
+def test_state_dict_keys_match_reference():
+    g = load("encoder.npz")
+    for tag, cfg in (("default", cases.CFG_DEFAULT), ("cfg2", cases.CFG_BASELINE_SH)):
+        ref_keys = set(g[f"{tag}.state_dict_keys"].tolist())
+        mine = set(cases.state_dict_shapes(cfg))
+        extra = ref_keys - mine
+        assert mine <= ref_keys
+        assert extra == {"audio_encoder.mel_preprocessor.mel_transform.spectrogram.window",
+                         "audio_encoder.mel_preprocessor.mel_transform.mel_scale.fb"}
+
+
+def test_infonce():
+    g = load("infonce.npz")
+    gen = torch.Generator().manual_seed(5)
+    for tag, n, d, nsong in (("pairs48", 48, 768, 24), ("gathered384", 384, 768, 192), ("triples", 12, 16, 4)):
+        e = torch.randn(n, d, generator=gen)
+        close(cases.checksum(e), g[f"{tag}.emb_checksum"], rtol=1e-12, atol=0)
+        close(oloss.info_nce(e, torch.arange(n) % nsong, 0.1).item(), g[f"{tag}.loss"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        oloss.info_nce(torch.randn(4, 8), torch.arange(4))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5, 11])
+def test_augment_trace_and_audio(seed):
+    g = load("augment.npz")
+    x = cases.feature_case("synth1", 33075)
+    real_rand = torch.rand
+    draws = []
+
+    def rand(*a, **k):
+        v = real_rand(*a, **k)
+        draws.append(float(v.flatten()[0]))
+        return v
+
+    torch.manual_seed(seed)
+    torch.rand = rand
+    try:
+        y, trace = oaug.augment_stems(omel.tensor_to_stems_dict(x))
+    finally:
+        torch.rand = real_rand
+    # RNG consumption (decisions) bit-exact
+    assert np.array_equal(np.array(draws, dtype=np.float64), g[f"seed{seed}.rand_draws"])
+    assert int(g[f"seed{seed}.reverb"]) == int("reverb_ir" in trace)
+    y8 = omel.stems_dict_to_tensor(y)
+    idx = torch.from_numpy(g[f"seed{seed}.idx"])
+    close(y8.flatten()[idx].numpy(), g[f"seed{seed}.samples"], rtol=1e-5, atol=1e-6)
+    close(y8.double().sum(-1).numpy(), g[f"seed{seed}.chan_sum"], rtol=1e-5, atol=1e-3)
+    close((y8.double() ** 2).sum(-1).numpy(), g[f"seed{seed}.chan_sqsum"], rtol=1e-5, atol=1e-6)
+
+
+def test_augment_single_effects():
+    g = load("augment.npz")
+    x = cases.feature_case("synth1", 33075)[4:6]
+    close(oaug.compress(x).numpy()[:, :4096], g["compress.samples"], rtol=1e-6, atol=1e-8)
+    torch.manual_seed(123)
+    close(oaug.reverb(x, oaug.make_ir(44100)).numpy()[:, :4096], g["reverb.out_head"], rtol=1e-5, atol=1e-6)
