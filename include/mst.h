@@ -1,0 +1,165 @@
+/*
+ * mst.h -- C ABI of libmst.so: MI355X (gfx950) kernels for the contrastive data path of
+ * barry-mir/mixing-style-transfer (waveform stems -> [augment] -> STFT -> mel -> 64-d mixing
+ * features -> FiLM band-split CNN encoder -> embedding -> InfoNCE).
+ *
+ * The reference is 100 % Python and has no FFI; the drop-in boundary is its Python call
+ * contract.  Each entry point below names the reference code whose
+ * arithmetic it replaces (paths relative to the reference repo).  The Python mirror of the
+ * reference classes (mixing-style-transfer_amd/{mixing_utils,model,loss,data}.py) binds these
+ * through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; all `dev` pointers are HIP device pointers owned by the caller
+ *     (PyTorch), all `host` pointers are ordinary host memory read during the call only;
+ *   - every function returns 0 on success, a negative MST_E* code otherwise, and never throws;
+ *     mst_last_error() returns a thread-local description of the last failure;
+ *   - the library allocates device memory only inside plan/encoder handles (constant tables and
+ *     weights); per-call scratch is a caller-provided workspace (query the size first);
+ *   - launches are asynchronous on the given `hipStream_t` (passed as void*; NULL = default
+ *     stream), never synchronise, and are safe to capture into a hipGraph;
+ *   - handles are immutable after creation and may be shared by concurrent streams as long as
+ *     each in-flight call has its own workspace.
+ */
+#ifndef MST_H_
+#define MST_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MST_ABI_VERSION 1
+
+#define MST_OK 0
+#define MST_EINVAL (-1)   /* bad argument (shape, NULL pointer, unsupported n_fft ...) */
+#define MST_ENOMEM (-2)   /* workspace too small / device allocation failed          */
+#define MST_EHIP (-3)     /* a HIP runtime call or kernel launch failed               */
+
+int mst_version(void);
+const char* mst_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage A: STFT -> mel -> log-mel + mixing features.
+ * Replaces: torchaudio MelSpectrogram as called at src/mixing_utils.py:159,280 and
+ * src/model.py:58-65; MixingFeatureExtractor.extract_all_features src/mixing_utils.py:71-105
+ * (extract_dynamics :107-139, extract_spectral :141-236, extract_stereo :238-268,
+ * extract_masking :270-309, compute_loudness :311-318, _flatten_features :320-357).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mst_plan mst_plan;
+
+/* window: host [n_fft] analysis window (periodic Hann in the reference);
+ * fb:     host [n_fft/2+1][n_mels] row-major mel filterbank exactly as the host framework built
+ *         it (torchaudio melscale_fbanks, fp32); each mel band must have contiguous support.
+ * detailed_bins: 0 = reference default (5 spectral features/stem, feature_dim 64);
+ *         n>0 = use_detailed_spectral mode with n_spectral_bins=n (feature_dim 4*(9+n+2)+8).
+ * n_fft in {512,1024,2048}; n_mels <= 256; hop >= 1.                                    */
+int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_mels,
+                    const float* window, const float* fb, int detailed_bins);
+void mst_plan_destroy(mst_plan* plan);
+int mst_plan_frames(const mst_plan* plan, int T);      /* 1 + T / hop (center=True)            */
+int mst_plan_feature_dim(const mst_plan* plan);
+size_t mst_melfeat_workspace_bytes(const mst_plan* plan, int B, int T);
+
+/* stems:  dev [B][8][T] fp32, channel order vocals L,R, bass L,R, drums L,R, other L,R.
+ * logmel: dev [B][8][n_mels][frames] fp32 = log(mel + 1e-10)  (may be NULL: features only)
+ * feats:  dev [B][feature_dim] fp32 in the reference's sorted-key layout (may be NULL)
+ * Requires T > n_fft/2 (reflect padding), same as torch.stft.                               */
+int mst_melfeat_forward(const mst_plan* plan, const float* stems, int B, int T, float* logmel,
+                        float* feats, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stage B: FiLM MLP + band-split Conv2D/BN/FiLM/ReLU/MaxPool x2 + attention pooling (eval).
+ * Replaces: MixingFeatureEncoder.forward src/model.py:410-464, SubSpectrogramCNN.forward
+ * :127-157 (x n_subbands, loop :345-362), concat/view :332-367, AttentionPooling.forward
+ * :187-211.  BatchNorm uses running statistics, Dropout is identity (model.eval()).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mst_encoder mst_encoder;
+
+typedef struct mst_encoder_config {
+  int32_t n_mels, split_size, overlap, n_subbands;
+  int32_t feature_dim, embed_dim;
+  int32_t film_hidden;  /* 256: feature_mlp width        (src/model.py:385-408) */
+  int32_t attn_hidden;  /* 256: attention hidden width   (src/model.py:284-288) */
+  float bn_eps;         /* 1e-5                                                   */
+} mst_encoder_config;
+
+/* All pointers: host fp32, tensors exactly as in the reference state_dict.                   */
+typedef struct mst_encoder_weights {
+  /* per sub-band i: audio_encoder.subnet_cnns.{i}.* , concatenated over i                    */
+  const float* conv1_w;  /* [n_sub][32][8][7][7]  */
+  const float* conv1_b;  /* [n_sub][32]           */
+  const float* bn1_w, *bn1_b, *bn1_mean, *bn1_var; /* [n_sub][32] */
+  const float* conv2_w;  /* [n_sub][64][32][7][7] */
+  const float* conv2_b;  /* [n_sub][64]           */
+  const float* bn2_w, *bn2_b, *bn2_mean, *bn2_var; /* [n_sub][64] */
+  /* film_encoder.* */
+  const float* mlp0_w, *mlp0_b;   /* feature_mlp.0  [H][feature_dim], [H] */
+  const float* mlp3_w, *mlp3_b;   /* feature_mlp.3  [H][H], [H]           */
+  const float* head_w, *head_b;   /* film_head      [n_sub*192][H], [n_sub*192] */
+  /* audio_encoder.attention_pooling.* ; C = 64*n_sub*freq_dim */
+  const float* att0_w, *att0_b;   /* attention.0   [A][C], [A] */
+  const float* att2_w, *att2_b;   /* attention.2   [1][A], [1] */
+  const float* proj_w, *proj_b;   /* projection.0  [E][C], [E] */
+} mst_encoder_weights;
+
+/* Optional device outputs for intermediate activations (parity tests); any may be NULL.      */
+typedef struct mst_encoder_taps {
+  float* film;     /* dev [B][n_sub*192]                      */
+  float* pool1;    /* dev [B][n_sub][32][H1][W1]              */
+  float* pool_in;  /* dev [B][64*n_sub*freq_dim][W2]  (input of attention pooling) */
+} mst_encoder_taps;
+
+int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg,
+                       const mst_encoder_weights* w);
+void mst_encoder_destroy(mst_encoder* enc);
+size_t mst_encoder_workspace_bytes(const mst_encoder* enc, int B, int frames);
+/* logmel: dev [B][8][n_mels][frames]; feats: dev [B][feature_dim]; emb: dev [B][embed_dim]  */
+int mst_encoder_forward(const mst_encoder* enc, const float* logmel, int frames, const float* feats,
+                        int B, float* emb, const mst_encoder_taps* taps, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Augmentation chain.  Replaces AudioAugmenter.augment_stems src/mixing_utils.py:376-419 and
+ * apply_spectral_tilt :421-433, apply_compression :435-447, apply_bandwidth_limit :449-456,
+ * apply_reverb :458-479.  Every random decision is drawn by the HOST in the reference's order
+ * with the reference's RNG (torch CPU generator) and passed in; the kernels are deterministic.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mst_aug_stem {
+  float gain;          /* linear gain, 1.0f = none             (:389-392)                   */
+  int32_t tilt;        /* 0 none, 1 section in tilt_sos        (:421-433)                   */
+  int32_t compress;    /* 0/1: 4:1 above -20 dB                (:435-447)                   */
+  int32_t bw_sections; /* 0 none, else #biquads in bw_sos (2)  (:449-456)                   */
+  double tilt_sos[6];  /* scipy.signal.butter(..., output='sos') rows b0 b1 b2 a0 a1 a2     */
+  double bw_sos[12];
+} mst_aug_stem;
+
+typedef struct mst_aug_clip {
+  mst_aug_stem stem[4];
+  int32_t reverb;      /* 0/1: reverb of the summed mix, redistributed (:404-417)           */
+  int32_t pad_;
+} mst_aug_clip;
+
+size_t mst_aug_workspace_bytes(int B, int T, int ir_len);
+/* stems_inout: dev [B][8][T] modified in place; decisions: host [B];
+ * reverb_ir:   dev [B][ir_len] (rows of clips with reverb==0 are ignored; may be NULL if none) */
+int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inout,
+                  const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * InfoNCE forward on (gathered) embeddings.  Replaces InfoNCELoss.forward src/loss.py:31-136.
+ * emb: dev [N][D] fp32; labels: dev [N] int64; anchors [row0,row0+rows) are the local rows.
+ * out: dev [2] = { sum over valid local anchors of -log(pos/(pos+neg+1e-8)), #valid anchors }.
+ * ------------------------------------------------------------------------------------------ */
+size_t mst_infonce_workspace_bytes(int N, int D);
+int mst_infonce_forward(const float* emb, const int64_t* labels, int N, int D, int row0, int rows,
+                        float temperature, float* out, void* workspace, size_t workspace_bytes,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MST_H_ */

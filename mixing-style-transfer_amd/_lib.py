@@ -1,0 +1,122 @@
+"""ctypes binding of libmst.so (C ABI declared in include/mst.h) + in-tree build helper.
+
+The product path fails loudly when the HIP library is missing or a call fails: there is no
+CPU / PyTorch fallback for the kernels.
+"""
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmst.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MST_OK = 0
+
+
+class MstError(RuntimeError):
+    pass
+
+
+class EncoderConfig(C.Structure):
+    _fields_ = [("n_mels", C.c_int32), ("split_size", C.c_int32), ("overlap", C.c_int32),
+                ("n_subbands", C.c_int32), ("feature_dim", C.c_int32), ("embed_dim", C.c_int32),
+                ("film_hidden", C.c_int32), ("attn_hidden", C.c_int32), ("bn_eps", C.c_float)]
+
+
+_W_FIELDS = ["conv1_w", "conv1_b", "bn1_w", "bn1_b", "bn1_mean", "bn1_var",
+             "conv2_w", "conv2_b", "bn2_w", "bn2_b", "bn2_mean", "bn2_var",
+             "mlp0_w", "mlp0_b", "mlp3_w", "mlp3_b", "head_w", "head_b",
+             "att0_w", "att0_b", "att2_w", "att2_b", "proj_w", "proj_b"]
+
+
+class EncoderWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _W_FIELDS]
+
+
+class EncoderTaps(C.Structure):
+    _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p)]
+
+
+class AugStem(C.Structure):
+    _fields_ = [("gain", C.c_float), ("tilt", C.c_int32), ("compress", C.c_int32), ("bw_sections", C.c_int32),
+                ("tilt_sos", C.c_double * 6), ("bw_sos", C.c_double * 12)]
+
+
+class AugClip(C.Structure):
+    _fields_ = [("stem", AugStem * 4), ("reverb", C.c_int32), ("pad_", C.c_int32)]
+
+
+# every symbol include/mst.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mst_version": (C.c_int, []),
+    "mst_last_error": (C.c_char_p, []),
+    "mst_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int]),
+    "mst_plan_destroy": (None, [C.c_void_p]),
+    "mst_plan_frames": (C.c_int, [C.c_void_p, C.c_int]),
+    "mst_plan_feature_dim": (C.c_int, [C.c_void_p]),
+    "mst_melfeat_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "mst_melfeat_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    "mst_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EncoderConfig), C.POINTER(EncoderWeights)]),
+    "mst_encoder_destroy": (None, [C.c_void_p]),
+    "mst_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "mst_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.POINTER(EncoderTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_aug_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mst_aug_apply": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                C.c_size_t, C.c_void_p]),
+    "mst_infonce_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mst_infonce_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libmst.so next to this file (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j8"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=not verbose)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise MstError("building libmst.so failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    """Load libmst.so (must have been built: `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise MstError(f"{LIB_PATH} not found: the HIP extension is not built. Run __graft_entry__.build() "
+                               f"(make -C {CSRC}). There is no CPU fallback.")
+            h = C.CDLL(LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(h, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = h
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != MST_OK:
+        msg = lib().mst_last_error()
+        raise MstError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dptr(t):
+    """Device (or host) pointer of a contiguous tensor, or NULL."""
+    return C.c_void_p(0 if t is None else t.data_ptr())

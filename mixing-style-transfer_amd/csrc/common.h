@@ -1,0 +1,62 @@
+// Shared host/device helpers for libmst.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "mst.h"
+
+namespace mst {
+
+// thread-local last-error string behind mst_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+#define MST_HIP_CHECK(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return ::mst::fail(MST_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                         __FILE__, __LINE__);                                                 \
+  } while (0)
+
+#define MST_REQUIRE(cond, ...)                                                                \
+  do {                                                                                        \
+    if (!(cond)) return ::mst::fail(MST_EINVAL, __VA_ARGS__);                                 \
+  } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <typename T>
+int upload(T** dst, const T* host, size_t n) {
+  *dst = nullptr;
+  if (n == 0) return MST_OK;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), n * sizeof(T));
+  if (e != hipSuccess) return fail(MST_ENOMEM, "hipMalloc(%zu B) failed: %s", n * sizeof(T), hipGetErrorString(e));
+  e = hipMemcpy(*dst, host, n * sizeof(T), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return fail(MST_EHIP, "hipMemcpy H2D failed: %s", hipGetErrorString(e));
+  return MST_OK;
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give every XCD a contiguous run of
+// logical work items so neighbouring tiles hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace mst

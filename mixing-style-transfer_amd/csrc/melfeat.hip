@@ -1,0 +1,872 @@
+// Stage A: waveform -> windowed real FFT -> |X|^2 -> sparse HTK mel -> log-mel + mixing-feature
+// partial sums, and the finalise kernel that turns the partials into the 64-d feature vector.
+//
+// Replaces (reference barry-mir/mixing-style-transfer): torchaudio MelSpectrogram as called at
+// src/mixing_utils.py:159,280 and src/model.py:58-65; MixingFeatureExtractor src/mixing_utils.py:71-357.
+//
+// Kernel shape (gfx950, wave64):
+//   * one workgroup = 4 waves = one (clip, run of frames); blockIdx is XCD-remapped so the runs of
+//     one clip sit on one XCD (overlapping frame reads and partial output lines meet in one L2);
+//   * one wave = one real n_fft-point FFT at a time, as an n_fft/2-point complex Stockham FFT
+//     held in registers (radix-8/4 butterflies), exchanged through a wave-private LDS scratch
+//     between passes; twiddles / window / sparse mel weights live in LDS tables;
+//   * each sample is read from HBM once (frames overlap 4x, re-reads hit L1/L2), each log-mel
+//     value is written once, staged through an LDS tile so that stores are frame-contiguous;
+//   * all feature statistics (per-band dB sums, flatness sums, inter-stem masking, waveform
+//     moments) are accumulated in registers in the same pass and reduced per workgroup.
+#include "common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int kWaves = 4;              // waves per workgroup
+constexpr int kFPW = 4;                // frames per wave per batch
+constexpr int kTF = kWaves * kFPW;     // frames per workgroup batch (one LDS tile flush)
+constexpr int kTileStride = kTF + 1;   // +1: conflict-free transposed tile writes
+constexpr int kThreads = kWaves * 64;
+constexpr int kNumScalars = 80;        // scalar slots per partial record (see enum below)
+
+// scalar slots of a partial record, after the 4*M per-band sums
+enum : int {
+  S_LOGSUM = 0,   // [4] sum log(mel+1e-10) over (2 ch, M, frames)
+  S_LINSUM = 4,   // [4] sum mel
+  S_MASK = 8,     // [4] sum sigmoid(max_other - own)
+  S_SQ = 12,      // [8] sum x^2
+  S_PEAK = 20,    // [8] max |x|
+  S_DSUM = 28,    // [8] sum (x - pivot)
+  S_DSQ = 36,     // [8] sum (x - pivot)^2
+  S_PIVOT = 44,   // [8] pivot (first owned sample)
+  S_CROSS = 52,   // [4] sum (L - pL)(R - pR)
+  S_MID = 56,     // [4] sum (L + R)^2
+  S_SIDE = 60,    // [4] sum (L - R)^2
+  S_MIX = 64,     // [1] sum over both channels of (v + b + d + o)^2
+  S_NSAMP = 65,   // [1] owned samples
+  S_NFRAME = 66,  // [1] frames in this run
+};
+
+struct LaneBand {  // one mel band owned by a lane
+  int band, start, len, woff;
+};
+
+struct KParams {
+  const float* stems;
+  float* logmel;
+  float* partials;
+  const float* window;
+  const float2* tw;
+  const float2* post;
+  const float* melw;
+  const LaneBand* lanebands;  // [NB][64]
+  int B, T, F, M, hop;
+  int tw_count, nnz;
+  int frames_per_run, runs_per_clip, pstride;
+  int vec_ok;  // 8-byte aligned float2 frame loads allowed
+  int vec4_ok; // 16-byte aligned float4 stats loads allowed
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <int R>
+struct Dft;
+template <>
+struct Dft<2> {
+  static __device__ __forceinline__ void run(float2* v) {
+    float2 a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  }
+};
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+  float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+  float2 t3 = make_float2(d.y, -d.x);  // (a1 - a3) * (-i)
+  a0 = cadd(t0, t2);
+  a2 = csub(t0, t2);
+  a1 = cadd(t1, t3);
+  a3 = csub(t1, t3);
+}
+template <>
+struct Dft<4> {
+  static __device__ __forceinline__ void run(float2* v) { dft4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct Dft<8> {
+  static __device__ __forceinline__ void run(float2* v) {
+    constexpr float h = 0.70710678118654752440f;
+    dft4(v[0], v[2], v[4], v[6]);  // even part  -> e0..e3 in v0,v2,v4,v6
+    dft4(v[1], v[3], v[5], v[7]);  // odd part   -> o0..o3 in v1,v3,v5,v7
+    float2 o0 = v[1];
+    float2 o1 = make_float2((v[3].x + v[3].y) * h, (v[3].y - v[3].x) * h);   // * W8^1
+    float2 o2 = make_float2(v[5].y, -v[5].x);                                // * W8^2 = -i
+    float2 o3 = make_float2((v[7].y - v[7].x) * h, -(v[7].x + v[7].y) * h);  // * W8^3
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    v[0] = cadd(e0, o0);
+    v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1);
+    v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2);
+    v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3);
+    v[7] = csub(e3, o3);
+  }
+};
+
+__device__ __forceinline__ int pad8(int e) { return e + (e >> 3); }
+
+// One Stockham pass of radix R with sub-transform length NS (product of earlier radices).
+// Butterfly j = lane + 64*u takes x[j + t*NC/R], multiplies by W_{NS*R}^{(j % NS) t} and writes
+// y[(j / NS) * NS * R + j % NS + t * NS].  The LAST pass leaves natural order in registers:
+// v[u*R + t] = X[lane + 64*(u + t*NBF)].
+template <int NC, int R, int NS, bool FIRST, bool LAST>
+__device__ __forceinline__ void fft_pass(float2 (&v)[NC / 64], float2* scr, const float2* tw, int lane) {
+  constexpr int NBF = NC / R / 64;
+  constexpr int STR = NC / R;
+  if constexpr (!FIRST) {
+#pragma unroll
+    for (int u = 0; u < NBF; ++u)
+#pragma unroll
+      for (int t = 0; t < R; ++t) v[u * R + t] = scr[pad8(lane + 64 * u + t * STR)];
+  }
+#pragma unroll
+  for (int u = 0; u < NBF; ++u) {
+    if constexpr (NS > 1) {
+#pragma unroll
+      for (int t = 1; t < R; ++t) v[u * R + t] = cmul(v[u * R + t], tw[(u * (R - 1) + (t - 1)) * 64 + lane]);
+    }
+    Dft<R>::run(&v[u * R]);
+  }
+  if constexpr (!LAST) {
+#pragma unroll
+    for (int u = 0; u < NBF; ++u) {
+      const int j = lane + 64 * u;
+      const int base = (j / NS) * NS * R + (j % NS);
+#pragma unroll
+      for (int t = 0; t < R; ++t) scr[pad8(base + t * NS)] = v[u * R + t];
+    }
+  }
+}
+
+// Radix plan per complex length.  R0 is the first-pass radix (fixes the register order of the
+// windowed input), RL the last (fixes the register order of the spectrum).
+template <int NC>
+struct FftPlan;
+template <>
+struct FftPlan<256> {
+  static constexpr int R0 = 4, RL = 4;
+  static constexpr int TW = 3 * 3 * 64;
+  static __device__ __forceinline__ void run(float2 (&v)[4], float2* scr, const float2* tw, int lane) {
+    fft_pass<256, 4, 1, true, false>(v, scr, tw, lane);
+    fft_pass<256, 4, 4, false, false>(v, scr, tw, lane);
+    fft_pass<256, 4, 16, false, false>(v, scr, tw + 3 * 64, lane);
+    fft_pass<256, 4, 64, false, true>(v, scr, tw + 2 * 3 * 64, lane);
+  }
+};
+template <>
+struct FftPlan<512> {
+  static constexpr int R0 = 8, RL = 8;
+  static constexpr int TW = 2 * 7 * 64;
+  static __device__ __forceinline__ void run(float2 (&v)[8], float2* scr, const float2* tw, int lane) {
+    fft_pass<512, 8, 1, true, false>(v, scr, tw, lane);
+    fft_pass<512, 8, 8, false, false>(v, scr, tw, lane);
+    fft_pass<512, 8, 64, false, true>(v, scr, tw + 7 * 64, lane);
+  }
+};
+template <>
+struct FftPlan<1024> {
+  static constexpr int R0 = 8, RL = 4;
+  static constexpr int TW = 2 * 7 * 64 + 4 * 3 * 64 + 4 * 3 * 64;
+  static __device__ __forceinline__ void run(float2 (&v)[16], float2* scr, const float2* tw, int lane) {
+    fft_pass<1024, 8, 1, true, false>(v, scr, tw, lane);
+    fft_pass<1024, 8, 8, false, false>(v, scr, tw, lane);
+    fft_pass<1024, 4, 64, false, false>(v, scr, tw + 2 * 7 * 64, lane);
+    fft_pass<1024, 4, 256, false, true>(v, scr, tw + 2 * 7 * 64 + 4 * 3 * 64, lane);
+  }
+};
+__device__ __forceinline__ int reflect_idx(int i, int T) { return i < 0 ? -i : (i >= T ? 2 * (T - 1) - i : i); }
+
+__device__ __forceinline__ float2 shfl2(float2 a, int src) {
+  return make_float2(__shfl(a.x, src, 64), __shfl(a.y, src, 64));
+}
+
+// mel power of one (channel, frame): returns this lane's NB band values.
+template <int NFFT, int NB>
+__device__ __forceinline__ void frame_mel(const KParams& p, const float* __restrict__ xch, int frame, int lane,
+                                          const float2* s_win, const float2* s_tw, const float2* s_post,
+                                          const float* s_melw, float2* scr, const LaneBand (&lb)[NB],
+                                          float (&mel)[NB]) {
+  constexpr int NC = NFFT / 2;
+  constexpr int Q = NC / 64;
+  using Plan = FftPlan<NC>;
+  constexpr int R0 = Plan::R0, RL = Plan::RL;
+  constexpr int NBF0 = NC / R0 / 64, STR0 = NC / R0, NBFL = NC / RL / 64;
+  float2 v[Q];
+  const int s0 = frame * p.hop - NFFT / 2;
+  const bool interior = (s0 >= 0) && (s0 + NFFT <= p.T);
+  if (interior && p.vec_ok) {
+    const float2* x2 = reinterpret_cast<const float2*>(xch + s0);
+#pragma unroll
+    for (int u = 0; u < NBF0; ++u)
+#pragma unroll
+      for (int t = 0; t < R0; ++t) {
+        const int n = lane + 64 * u + t * STR0;
+        const float2 x = x2[n], w = s_win[n];
+        v[u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
+      }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NBF0; ++u)
+#pragma unroll
+      for (int t = 0; t < R0; ++t) {
+        const int n = lane + 64 * u + t * STR0;
+        const int i0 = s0 + 2 * n;
+        const float xa = xch[reflect_idx(i0, p.T)], xb = xch[reflect_idx(i0 + 1, p.T)];
+        const float2 w = s_win[n];
+        v[u * R0 + t] = make_float2(xa * w.x, xb * w.y);
+      }
+  }
+  Plan::run(v, scr, s_tw, lane);
+
+  // real-FFT split: X[k] = E + W^k O with E,O from Z[k] and conj(Z[NC-k]); P = |X|^2
+  float* P = reinterpret_cast<float*>(scr);
+  const int mirror = (64 - lane) & 63;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    auto reg = [](int qq) { return (qq % NBFL) * RL + qq / NBFL; };
+    const float2 a = v[reg(q)];
+    const float2 bo = shfl2(v[reg(Q - 1 - q)], mirror);
+    const float2 bs = v[reg((Q - q) % Q)];
+    const float2 b = lane == 0 ? bs : bo;
+    const float2 w = s_post[q * 64 + lane];
+    const float ex = 0.5f * (a.x + b.x), ey = 0.5f * (a.y - b.y);
+    const float ox = 0.5f * (a.y + b.y), oy = -0.5f * (a.x - b.x);
+    const float xr = ex + (w.x * ox - w.y * oy);
+    const float xi = ey + (w.x * oy + w.y * ox);
+    P[lane + 64 * q] = xr * xr + xi * xi;
+  }
+  if (lane == 0) {
+    const float2 z0 = v[0];
+    const float ny = z0.x - z0.y;
+    P[NC] = ny * ny;
+  }
+  // sparse mel: each lane gathers its bands' contiguous supports
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    float acc = 0.f;
+    const float* w = s_melw + lb[r].woff;
+    const float* pp = P + lb[r].start;
+    for (int i = 0; i < lb[r].len; ++i) acc = fmaf(w[i], pp[i], acc);
+    mel[r] = acc;
+  }
+}
+
+template <int NFFT, int NB>
+__global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
+  constexpr int NC = NFFT / 2;
+  constexpr int SCR = NC + NC / 8;  // padded float2 per wave
+  constexpr float kLn2 = 0.69314718055994530942f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* s_win = reinterpret_cast<float2*>(smem);           // [NC] float2 = window pairs
+  float2* s_tw = s_win + NC;                                   // [tw_count]
+  float2* s_post = s_tw + p.tw_count;                          // [NC]
+  float2* s_scr = s_post + NC;                                 // [kWaves][SCR]
+  float* s_melw = reinterpret_cast<float*>(s_scr + kWaves * SCR);  // [nnz padded to 4]
+  float* s_tile = s_melw + ((p.nnz + 3) & ~3);                 // [2*M][kTileStride]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int work = mst::xcd_remap(blockIdx.x, gridDim.x);
+  const int clip = work / p.runs_per_clip, run = work % p.runs_per_clip;
+  const int f_begin = run * p.frames_per_run;
+  const int f_end = min(p.F, f_begin + p.frames_per_run);
+  const int M = p.M;
+
+  // ---- tables -> LDS
+  {
+    const float2* gw = reinterpret_cast<const float2*>(p.window);
+    for (int i = tid; i < NC; i += kThreads) s_win[i] = gw[i];
+    for (int i = tid; i < p.tw_count; i += kThreads) s_tw[i] = p.tw[i];
+    for (int i = tid; i < NC; i += kThreads) s_post[i] = p.post[i];
+    for (int i = tid; i < p.nnz; i += kThreads) s_melw[i] = p.melw[i];
+  }
+  LaneBand lb[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) lb[r] = p.lanebands[r * 64 + lane];
+
+  const float* xclip = p.stems + (size_t)clip * 8 * p.T;
+  float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
+  float* red = reinterpret_cast<float*>(s_scr);  // workgroup reduction buffer (aliases FFT scratch)
+
+  // ---- waveform moments over the samples this run owns: [f_begin*hop, f_end*hop) (last run: to T)
+  {
+    const int o_begin = f_begin * p.hop;
+    const int o_end = (f_end == p.F) ? p.T : min(p.T, f_end * p.hop);
+    const int n_own = max(0, o_end - o_begin);
+    float piv[8], sq[8], pk[8], ds[8], dq[8], cr[4], mid[4], side[4], mix = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      piv[c] = n_own > 0 ? xclip[(size_t)c * p.T + o_begin] : 0.f;
+      sq[c] = pk[c] = ds[c] = dq[c] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) cr[s] = mid[s] = side[s] = 0.f;
+    for (int i = tid * 4; i < n_own; i += kThreads * 4) {
+      float x[8][4];
+      const bool full = (i + 3 < n_own);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float* src = xclip + (size_t)c * p.T + o_begin + i;
+        if (full && p.vec4_ok) {
+          const float4 q = *reinterpret_cast<const float4*>(src);
+          x[c][0] = q.x, x[c][1] = q.y, x[c][2] = q.z, x[c][3] = q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[c][e] = (i + e < n_own) ? src[e] : piv[c];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (i + e < n_own) {
+          float mL = 0.f, mR = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float L = x[2 * s][e], R = x[2 * s + 1][e];
+            const float dL = L - piv[2 * s], dR = R - piv[2 * s + 1];
+            sq[2 * s] = fmaf(L, L, sq[2 * s]);
+            sq[2 * s + 1] = fmaf(R, R, sq[2 * s + 1]);
+            pk[2 * s] = fmaxf(pk[2 * s], fabsf(L));
+            pk[2 * s + 1] = fmaxf(pk[2 * s + 1], fabsf(R));
+            ds[2 * s] += dL;
+            ds[2 * s + 1] += dR;
+            dq[2 * s] = fmaf(dL, dL, dq[2 * s]);
+            dq[2 * s + 1] = fmaf(dR, dR, dq[2 * s + 1]);
+            cr[s] = fmaf(dL, dR, cr[s]);
+            const float sm = L + R, sd = L - R;
+            mid[s] = fmaf(sm, sm, mid[s]);
+            side[s] = fmaf(sd, sd, side[s]);
+            mL += L;  // python sum(): ((v + b) + d) + o
+            mR += R;
+          }
+          mix = fmaf(mL, mL, mix);
+          mix = fmaf(mR, mR, mix);
+        }
+      }
+    }
+    // workgroup reduce: 53 sums + 8 maxima
+    float vals[53];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vals[c] = sq[c], vals[8 + c] = ds[c], vals[16 + c] = dq[c];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vals[24 + s] = cr[s], vals[28 + s] = mid[s], vals[32 + s] = side[s];
+    vals[36] = mix;
+#pragma unroll
+    for (int k = 0; k < 37; ++k) {
+      const float r = mst::wave_sum(vals[k]);
+      if (lane == 0) red[wave * 48 + k] = r;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float r = mst::wave_max(pk[c]);
+      if (lane == 0) red[wave * 48 + 37 + c] = r;
+    }
+    __syncthreads();
+    if (tid < 45) {
+      float r = red[tid];
+      for (int w = 1; w < kWaves; ++w) r = tid < 37 ? r + red[w * 48 + tid] : fmaxf(r, red[w * 48 + tid]);
+      int slot;
+      if (tid < 8) slot = S_SQ + tid;
+      else if (tid < 16) slot = S_DSUM + (tid - 8);
+      else if (tid < 24) slot = S_DSQ + (tid - 16);
+      else if (tid < 28) slot = S_CROSS + (tid - 24);
+      else if (tid < 32) slot = S_MID + (tid - 28);
+      else if (tid < 36) slot = S_SIDE + (tid - 32);
+      else if (tid == 36) slot = S_MIX;
+      else slot = S_PEAK + (tid - 37);
+      part[4 * M + slot] = r;
+    }
+    if (tid < 8) part[4 * M + S_PIVOT + tid] = piv[tid];
+    if (tid == 0) {
+      part[4 * M + S_NSAMP] = (float)n_own;
+      part[4 * M + S_NFRAME] = (float)max(0, f_end - f_begin);
+    }
+    __syncthreads();  // red aliases the FFT scratch; tables are loaded too
+  }
+
+  // ---- spectral pass
+  float acc_db[4][NB], acc_log[4], acc_lin[4], acc_mask[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    acc_log[s] = acc_lin[s] = acc_mask[s] = 0.f;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) acc_db[s][r] = 0.f;
+  }
+  float2* scr = s_scr + wave * SCR;
+
+  for (int fb = f_begin; fb < f_end; fb += kTF) {
+    float S[4][kFPW][NB];  // channel-mean mel power per stem, frame slot, band
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int f = 0; f < kFPW; ++f)
+#pragma unroll
+        for (int r = 0; r < NB; ++r) S[s][f][r] = 0.f;
+
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll 1
+      for (int fi = 0; fi < kFPW; ++fi) {
+        const int frame = fb + wave * kFPW + fi;
+        if (frame >= f_end) continue;  // wave-uniform
+        float sm[NB];
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+          float mel[NB];
+          frame_mel<NFFT, NB>(p, xclip + (size_t)(2 * s + c) * p.T, frame, lane, s_win, s_tw, s_post, s_melw,
+                              scr, lb, mel);
+          float lsum = 0.f, msum = 0.f;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+            const bool ok = lb[r].band >= 0;
+            const float lm = __log2f(mel[r] + 1e-10f) * kLn2;
+            if (ok) {
+              s_tile[(c * M + lb[r].band) * kTileStride + wave * kFPW + fi] = lm;
+              lsum += lm;
+              msum += mel[r];
+            }
+            const float lmz = ok ? lm : 0.f;
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) acc_db[ss][r] += (s == ss) ? lmz : 0.f;
+            sm[r] = (c == 0) ? mel[r] : (sm[r] + mel[r]) * 0.5f;  // mel.mean(dim=0) of (2, M, F)
+          }
+#pragma unroll
+          for (int ss = 0; ss < 4; ++ss) {
+            acc_log[ss] += (s == ss) ? lsum : 0.f;
+            acc_lin[ss] += (s == ss) ? msum : 0.f;
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss)
+#pragma unroll
+          for (int ff = 0; ff < kFPW; ++ff)
+#pragma unroll
+            for (int r = 0; r < NB; ++r) S[ss][ff][r] = (s == ss && fi == ff) ? sm[r] : S[ss][ff][r];
+      }
+      __syncthreads();
+      if (p.logmel) {  // flush the stem's two channels: rows (c, band), kTF consecutive frames each
+        const int f = tid % kTF, frame = fb + f;
+        if (frame < f_end) {
+          for (int row = tid / kTF; row < 2 * M; row += kThreads / kTF) {
+            const int c = row / M, band = row - c * M;
+            p.logmel[(((size_t)clip * 8 + 2 * s + c) * M + band) * p.F + frame] = s_tile[row * kTileStride + f];
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // inter-stem masking for this wave's frames (mixing_utils.py:288-307)
+#pragma unroll
+    for (int ff = 0; ff < kFPW; ++ff) {
+      if (fb + wave * kFPW + ff >= f_end) continue;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        if (lb[r].band < 0) continue;
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+          float other = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j != ss) other = fmaxf(other, S[j][ff][r]);
+          const float d = S[ss][ff][r] - other;
+          acc_mask[ss] += 1.0f / (1.0f + __expf(d));  // sigmoid((0 - d) / 1)
+        }
+      }
+    }
+  }
+
+  // ---- workgroup reduction of the spectral accumulators
+  // per-band sums: same lane owns the same bands in every wave
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int r = 0; r < NB; ++r) red[((wave * 4 + s) * NB + r) * 64 + lane] = acc_db[s][r];
+  float* red2 = red + kWaves * 4 * NB * 64;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float a = mst::wave_sum(acc_log[s]), b = mst::wave_sum(acc_lin[s]), c = mst::wave_sum(acc_mask[s]);
+    if (lane == 0) {
+      red2[wave * 12 + S_LOGSUM + s] = a;
+      red2[wave * 12 + S_LINSUM + s] = b;
+      red2[wave * 12 + S_MASK + s] = c;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 4 * NB * 64; i += kThreads) {
+    const int l = i & 63, r = (i >> 6) % NB, s = i / (64 * NB);
+    float v = 0.f;
+    for (int w = 0; w < kWaves; ++w) v += red[((w * 4 + s) * NB + r) * 64 + l];
+    const int band = p.lanebands[r * 64 + l].band;
+    if (band >= 0) part[s * M + band] = v;
+  }
+  if (tid < 12) {
+    float v = 0.f;
+    for (int w = 0; w < kWaves; ++w) v += red2[w * 12 + tid];
+    part[4 * M + tid] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Finalise: reduce the per-run partial records of one clip in double precision and emit the
+// feature vector in the reference's sorted-key layout (mixing_utils.py:320-357).
+// ------------------------------------------------------------------------------------------
+struct FParams {
+  const float* partials;
+  float* feats;
+  int M, F, T, runs_per_clip, pstride, detailed_bins, feat_dim;
+};
+
+__device__ double pearson_vs_index(const double* y, int n) {
+  double my = 0;
+  for (int i = 0; i < n; ++i) my += y[i];
+  my /= n;
+  const double mx = 0.5 * (n - 1);
+  double sxy = 0, sxx = 0, syy = 0;
+  for (int i = 0; i < n; ++i) {
+    const double dx = i - mx, dy = y[i] - my;
+    sxy += dx * dy, sxx += dx * dx, syy += dy * dy;
+  }
+  const double std_unbiased = sqrt(syy / (n - 1));
+  if (std_unbiased < 1e-6) return 0.0;  // mixing_utils.py:184
+  double c = sxy / sqrt(sxx * syy);
+  return fmin(1.0, fmax(-1.0, c));      // torch.corrcoef clips to [-1, 1]
+}
+
+__global__ __launch_bounds__(256) void melfeat_finalize_kernel(const FParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* band = reinterpret_cast<double*>(smem);  // [4*M] mean dB per band
+  double* sc = band + 4 * p.M;                      // [kNumScalars] reduced scalars
+  double* chmean = sc + kNumScalars;                // [8]
+  double* chm2 = chmean + 8;                        // [8]
+  double* cross = chm2 + 8;                         // [4]
+  const int tid = threadIdx.x, clip = blockIdx.x, M = p.M;
+  const float* base = p.partials + (size_t)clip * p.runs_per_clip * p.pstride;
+  const double inv_n_db = 1.0 / (2.0 * p.F);
+  const double k_db = 10.0 / log(10.0);
+  for (int i = tid; i < 4 * M; i += 256) {
+    double s = 0;
+    for (int r = 0; r < p.runs_per_clip; ++r) s += base[(size_t)r * p.pstride + i];
+    band[i] = s * inv_n_db * k_db;  // mean over (2 ch, F) of 10*log10(mel + 1e-10)
+  }
+  if (tid < kNumScalars) {
+    const bool is_max = tid >= S_PEAK && tid < S_PEAK + 8;
+    double s = 0;
+    for (int r = 0; r < p.runs_per_clip; ++r) {
+      const double v = base[(size_t)r * p.pstride + 4 * M + tid];
+      s = is_max ? fmax(s, v) : s + v;
+    }
+    sc[tid] = s;
+  }
+  // pooled mean / M2 / cross moment from pivoted per-run sums (Chan et al. pairwise update)
+  if (tid < 8) {
+    double n = 0, mean = 0, m2 = 0;
+    for (int r = 0; r < p.runs_per_clip; ++r) {
+      const float* q = base + (size_t)r * p.pstride + 4 * M;
+      const double nr = q[S_NSAMP];
+      if (nr <= 0) continue;
+      const double sr = q[S_DSUM + tid], qr = q[S_DSQ + tid];
+      const double mr = q[S_PIVOT + tid] + sr / nr, m2r = fmax(0.0, qr - sr * sr / nr);
+      const double d = mr - mean, nt = n + nr;
+      m2 += m2r + d * d * n * nr / nt;
+      mean += d * nr / nt;
+      n = nt;
+    }
+    chmean[tid] = mean, chm2[tid] = m2;
+  } else if (tid >= 64 && tid < 68) {
+    const int s = tid - 64;
+    double n = 0, mL = 0, mR = 0, c = 0;
+    for (int r = 0; r < p.runs_per_clip; ++r) {
+      const float* q = base + (size_t)r * p.pstride + 4 * M;
+      const double nr = q[S_NSAMP];
+      if (nr <= 0) continue;
+      const double sL = q[S_DSUM + 2 * s], sR = q[S_DSUM + 2 * s + 1];
+      const double mLr = q[S_PIVOT + 2 * s] + sL / nr, mRr = q[S_PIVOT + 2 * s + 1] + sR / nr;
+      const double cr = q[S_CROSS + s] - sL * sR / nr;
+      const double dL = mLr - mL, dR = mRr - mR, nt = n + nr;
+      c += cr + dL * dR * n * nr / nt;
+      mL += dL * nr / nt, mR += dR * nr / nt;
+      n = nt;
+    }
+    cross[s] = c;
+  }
+  __syncthreads();
+
+  const int sd = p.detailed_bins > 0 ? p.detailed_bins + 2 : 5;
+  const int ps = 10 + sd;  // dynamics 6 + rel_loudness 1 + spectral + stereo 3
+  float* out = p.feats + (size_t)clip * p.feat_dim;
+  auto put = [&](int idx, double v) {
+    float f = (float)v;
+    f = fminf(fmaxf(f, -100.0f), 100.0f);  // clamp; fminf/fmaxf drop NaN like the NaN->0 step below
+    if (v != v) f = 0.0f;                  // NaN -> 0 (mixing_utils.py:343-348)
+    out[idx] = f;
+  };
+  const double n = (double)p.T;
+  auto loud = [&](double ms) { return -0.691 + 10.0 * log10(ms + 1e-10); };
+  if (tid < 4) {
+    const int s = tid;  // stem index in input order v,b,d,o ; sorted-key block order b,d,(mask),o,v
+    const int blk = (s == 1) ? 0 : (s == 2) ? ps : (s == 3) ? 2 * ps + 4 : 3 * ps + 4;
+    const double msL = sc[S_SQ + 2 * s] / n, msR = sc[S_SQ + 2 * s + 1] / n;
+    const double rmsL = sqrt(msL), rmsR = sqrt(msR);
+    const double l_stem = loud((sc[S_SQ + 2 * s] + sc[S_SQ + 2 * s + 1]) / (2 * n));
+    const double l_mix = loud(sc[S_MIX] / (2 * n));
+    // dynamics: rms L,R; crest L,R; loudness x2   (mixing_utils.py:107-139)
+    put(blk + 0, rmsL);
+    put(blk + 1, rmsR);
+    put(blk + 2, 20.0 * log10(sc[S_PEAK + 2 * s] / (rmsL + 1e-8)));
+    put(blk + 3, 20.0 * log10(sc[S_PEAK + 2 * s + 1] / (rmsR + 1e-8)));
+    put(blk + 4, l_stem);
+    put(blk + 5, l_stem);
+    put(blk + 6, l_stem - l_mix);  // rel_loudness (:94-97)
+    // spectral (:141-236)
+    const double* e = band + s * M;
+    const double cnt = 2.0 * M * p.F;
+    const double flat = exp(sc[S_LOGSUM + s] / cnt) / (sc[S_LINSUM + s] / cnt + 1e-10);
+    int o = blk + 7;
+    if (p.detailed_bins == 0) {
+      const int q = M / 4;
+      double lo = 0, mi = 0, hi = 0;
+      for (int i = 0; i < q; ++i) lo += e[i];
+      for (int i = q; i < 3 * q; ++i) mi += e[i];
+      for (int i = 3 * q; i < M; ++i) hi += e[i];
+      put(o + 0, lo / q);
+      put(o + 1, mi / (2 * q));
+      put(o + 2, hi / (M - 3 * q));
+      put(o + 3, pearson_vs_index(e, M));
+      put(o + 4, flat);
+    } else {
+      const int nb = p.detailed_bins;
+      double* curve = reinterpret_cast<double*>(smem) + 4 * M + kNumScalars + 24 + s * nb;
+      for (int i = 0; i < nb; ++i) {
+        if (nb >= M) { curve[i] = e[i]; continue; }
+        const float scale = nb > 1 ? (float)(M - 1) / (float)(nb - 1) : 0.f;  // align_corners=True
+        const float src = scale * i;
+        int i0 = (int)src;
+        if (i0 > M - 1) i0 = M - 1;
+        const int i1 = i0 + (i0 < M - 1 ? 1 : 0);
+        const double lam = src - (float)i0;
+        curve[i] = (1.0 - lam) * e[i0] + lam * e[i1];
+      }
+      for (int i = 0; i < nb; ++i) put(o + i, curve[i]);
+      put(o + nb, pearson_vs_index(curve, nb));
+      put(o + nb + 1, flat);
+    }
+    o = blk + 7 + sd;
+    // stereo (:238-268)
+    put(o + 0, 20.0 * log10(rmsL / (rmsR + 1e-8)));
+    put(o + 1, cross[s] / (sqrt(chm2[2 * s] * chm2[2 * s + 1]) + 1e-8));
+    put(o + 2, (sc[S_SIDE + s] / (4 * n)) / (sc[S_MID + s] / (4 * n) + 1e-8));
+    // masking (:270-309): block after drums
+    put(2 * ps + s, sc[S_MASK + s] / ((double)M * p.F));
+  }
+}
+
+template <int NFFT, int NB>
+hipError_t launch_melfeat(const KParams& kp, int grid, size_t lds, hipStream_t st) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_kernel<NFFT, NB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((melfeat_kernel<NFFT, NB>), dim3(grid), dim3(kThreads), lds, st, kp);
+  return hipGetLastError();
+}
+
+template <int NFFT>
+constexpr int tw_count_of() { return FftPlan<NFFT / 2>::TW; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct mst_plan {
+  int sr, n_fft, hop, n_mels, detailed_bins, feat_dim;
+  int nc, nb, nnz, tw_count;
+  int batches_per_run;
+  float* d_window = nullptr;
+  float2* d_tw = nullptr;
+  float2* d_post = nullptr;
+  float* d_melw = nullptr;
+  LaneBand* d_lanebands = nullptr;
+};
+
+namespace {
+
+void add_pass_tw(std::vector<float2>& tw, int NC, int R, int NS) {
+  if (NS == 1) return;
+  const int nbf = NC / R / 64;
+  for (int u = 0; u < nbf; ++u)
+    for (int t = 1; t < R; ++t)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int j = lane + 64 * u, k = j % NS;
+        const double a = -2.0 * M_PI * (double)(k * t) / (double)(NS * R);
+        tw.push_back(make_float2((float)cos(a), (float)sin(a)));
+      }
+}
+
+std::vector<std::pair<int, int>> passes_of(int NC) {
+  switch (NC) {
+    case 256: return {{4, 1}, {4, 4}, {4, 16}, {4, 64}};
+    case 512: return {{8, 1}, {8, 8}, {8, 64}};
+    case 1024: return {{8, 1}, {8, 8}, {4, 64}, {4, 256}};
+  }
+  return {};
+}
+
+int runs_per_clip(const mst_plan* p, int F) {
+  const int fpr = p->batches_per_run * kTF;
+  return (F + fpr - 1) / fpr;
+}
+int pstride_of(const mst_plan* p) { return 4 * p->n_mels + kNumScalars; }
+
+}  // namespace
+
+extern "C" {
+
+int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_mels, const float* window,
+                    const float* fb, int detailed_bins) {
+  MST_REQUIRE(out && window && fb, "mst_plan_create: NULL argument");
+  *out = nullptr;
+  MST_REQUIRE(n_fft == 512 || n_fft == 1024 || n_fft == 2048,
+              "mst_plan_create: n_fft=%d unsupported (512, 1024, 2048)", n_fft);
+  MST_REQUIRE(hop >= 1 && n_mels >= 4 && n_mels <= 256, "mst_plan_create: bad hop=%d / n_mels=%d", hop, n_mels);
+  MST_REQUIRE(detailed_bins >= 0 && detailed_bins <= 256 && (detailed_bins == 0 || detailed_bins < n_mels ||
+              detailed_bins == n_mels), "mst_plan_create: bad detailed_bins=%d", detailed_bins);
+  mst_plan* p = new mst_plan();
+  p->sr = sample_rate, p->n_fft = n_fft, p->hop = hop, p->n_mels = n_mels, p->detailed_bins = detailed_bins;
+  const int sd = detailed_bins > 0 ? detailed_bins + 2 : 5;
+  p->feat_dim = 4 * (10 + sd) + 4;
+  p->nc = n_fft / 2;
+  p->nb = n_mels <= 128 ? 2 : 4;
+  const char* env = getenv("MST_MELFEAT_BATCHES");
+  p->batches_per_run = env ? atoi(env) : 2;
+  if (p->batches_per_run < 1) p->batches_per_run = 1;
+  const int n_bins = n_fft / 2 + 1;
+
+  // sparse mel table: per band contiguous support [start, start+len)
+  std::vector<int> start(n_mels, 0), len(n_mels, 0), woff(n_mels, 0);
+  std::vector<float> melw;
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = -1, hi = -1;
+    for (int k = 0; k < n_bins; ++k)
+      if (fb[(size_t)k * n_mels + m] != 0.0f) {
+        if (lo < 0) lo = k;
+        hi = k;
+      }
+    woff[m] = (int)melw.size();
+    if (lo >= 0) {
+      start[m] = lo, len[m] = hi - lo + 1;
+      for (int k = lo; k <= hi; ++k) melw.push_back(fb[(size_t)k * n_mels + m]);
+    }
+  }
+  p->nnz = (int)melw.size();
+  if (melw.empty()) melw.push_back(0.f);
+  // lane -> bands: r even: r/2*128 + lane ; r odd: (r/2)*128 + 127 - lane  (pairs a narrow low band
+  // with a wide high band so the gather loop lengths are balanced across lanes)
+  std::vector<LaneBand> lbs((size_t)p->nb * 64);
+  for (int r = 0; r < p->nb; ++r)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = (r / 2) * 128 + ((r & 1) ? 127 - lane : lane);
+      LaneBand b{-1, 0, 0, 0};
+      if (m < n_mels) b = LaneBand{m, start[m], len[m], woff[m]};
+      lbs[(size_t)r * 64 + lane] = b;
+    }
+  std::vector<float2> tw;
+  for (auto pr : passes_of(p->nc)) add_pass_tw(tw, p->nc, pr.first, pr.second);
+  p->tw_count = (int)tw.size();
+  std::vector<float2> post(p->nc);
+  for (int q = 0; q < p->nc / 64; ++q)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int k = lane + 64 * q;
+      const double a = -2.0 * M_PI * (double)k / (double)n_fft;
+      post[(size_t)q * 64 + lane] = make_float2((float)cos(a), (float)sin(a));
+    }
+  int rc;
+  if ((rc = mst::upload(&p->d_window, window, (size_t)n_fft)) || (rc = mst::upload(&p->d_tw, tw.data(), tw.size())) ||
+      (rc = mst::upload(&p->d_post, post.data(), post.size())) ||
+      (rc = mst::upload(&p->d_melw, melw.data(), melw.size())) ||
+      (rc = mst::upload(&p->d_lanebands, lbs.data(), lbs.size()))) {
+    mst_plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return MST_OK;
+}
+
+void mst_plan_destroy(mst_plan* p) {
+  if (!p) return;
+  hipFree(p->d_window), hipFree(p->d_tw), hipFree(p->d_post), hipFree(p->d_melw), hipFree(p->d_lanebands);
+  delete p;
+}
+
+int mst_plan_frames(const mst_plan* p, int T) { return p ? 1 + T / p->hop : MST_EINVAL; }
+int mst_plan_feature_dim(const mst_plan* p) { return p ? p->feat_dim : MST_EINVAL; }
+
+size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
+  if (!p || B <= 0 || T <= 0) return 0;
+  const int F = 1 + T / p->hop;
+  return mst::align_up((size_t)B * runs_per_clip(p, F) * pstride_of(p) * sizeof(float), 256);
+}
+
+int mst_melfeat_forward(const mst_plan* p, const float* stems, int B, int T, float* logmel, float* feats,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(p && stems, "mst_melfeat_forward: NULL plan/stems");
+  MST_REQUIRE(B > 0 && T > p->n_fft / 2, "mst_melfeat_forward: need B>0 and T > n_fft/2 (reflect pad); B=%d T=%d", B, T);
+  MST_REQUIRE((long long)B * 8 * T < (1LL << 40), "mst_melfeat_forward: input too large");
+  const size_t need = mst_melfeat_workspace_bytes(p, B, T);
+  if (!workspace || workspace_bytes < need)
+    return mst::fail(MST_ENOMEM, "mst_melfeat_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int F = 1 + T / p->hop;
+  KParams kp{};
+  kp.stems = stems, kp.logmel = logmel, kp.partials = reinterpret_cast<float*>(workspace);
+  kp.window = p->d_window, kp.tw = p->d_tw, kp.post = p->d_post, kp.melw = p->d_melw, kp.lanebands = p->d_lanebands;
+  kp.B = B, kp.T = T, kp.F = F, kp.M = p->n_mels, kp.hop = p->hop;
+  kp.tw_count = p->tw_count, kp.nnz = p->nnz;
+  kp.frames_per_run = p->batches_per_run * kTF;
+  kp.runs_per_clip = runs_per_clip(p, F);
+  kp.pstride = pstride_of(p);
+  const bool base16 = (reinterpret_cast<uintptr_t>(stems) & 15) == 0;
+  kp.vec_ok = base16 && (T % 2 == 0) && (p->hop % 2 == 0);
+  kp.vec4_ok = base16 && (T % 4 == 0) && (p->hop % 4 == 0);
+  const int nc = p->nc;
+  size_t lds = (size_t)(nc + p->tw_count + nc + kWaves * (nc + nc / 8)) * sizeof(float2) +
+               (size_t)(((p->nnz + 3) & ~3) + 2 * p->n_mels * kTileStride) * sizeof(float);
+  // the reduction buffers alias the FFT scratch: kWaves*4*NB*64 + kWaves*12 floats must fit
+  const size_t red_need = (size_t)(kWaves * 4 * p->nb * 64 + kWaves * 12) * sizeof(float);
+  MST_REQUIRE(red_need <= (size_t)kWaves * (nc + nc / 8) * sizeof(float2), "internal: reduction buffer");
+  MST_REQUIRE(lds <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds);
+  const int grid = B * kp.runs_per_clip;
+  hipError_t e = hipErrorInvalidValue;
+#define MST_CASE(NF)                                                       \
+  case NF:                                                                 \
+    e = (p->nb == 2) ? launch_melfeat<NF, 2>(kp, grid, lds, st) : launch_melfeat<NF, 4>(kp, grid, lds, st); \
+    break;
+  switch (p->n_fft) {
+    MST_CASE(512)
+    MST_CASE(1024)
+    MST_CASE(2048)
+  }
+#undef MST_CASE
+  if (e != hipSuccess) return mst::fail(MST_EHIP, "melfeat_kernel launch failed: %s", hipGetErrorString(e));
+  if (feats) {
+    FParams fp{kp.partials, feats, p->n_mels, F, T, kp.runs_per_clip, kp.pstride, p->detailed_bins, p->feat_dim};
+    const size_t flds = (size_t)(4 * p->n_mels + kNumScalars + 24 + 4 * (p->detailed_bins > 0 ? p->detailed_bins : 0)) *
+                        sizeof(double);
+    hipLaunchKernelGGL(melfeat_finalize_kernel, dim3(B), dim3(256), flds, st, fp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return mst::fail(MST_EHIP, "melfeat_finalize_kernel launch failed: %s", hipGetErrorString(e));
+  }
+  return MST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+"""MI355X mirror of reference src/mixing_utils.py: MixingFeatureExtractor and AudioAugmenter.
+
+Same class names, constructor arguments, method names, return shapes and error behaviour as the
+reference; the arithmetic runs in libmst.so (HIP, gfx950).  Beyond the reference API the
+extractor is batched: `extract_all_features` accepts stems of shape (2, T) -> (feature_dim,)
+as the reference does, or (B, 2, T) -> (B, feature_dim), and `features_and_logmel` returns the
+model's log-mel input from the same pass over the waveform.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+STEMS = ("vocals", "bass", "drums", "other")
+
+
+def hann_window(n_fft: int) -> torch.Tensor:
+    return torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
+
+
+def melscale_fbanks_htk(n_freqs: int, n_mels: int, sample_rate: int) -> torch.Tensor:
+    """torchaudio.functional.melscale_fbanks(f_min=0, f_max=sr//2, norm=None, mel_scale='htk') in fp32 on the host
+    (the kernels consume this table; it is never re-derived on the device)."""
+    import math
+    freqs = torch.linspace(0, sample_rate // 2, n_freqs)
+    mel_max = 2595.0 * math.log10(1.0 + float(sample_rate // 2) / 700.0)
+    mel_pts = torch.linspace(0.0, mel_max, n_mels + 2)
+    hz = 700.0 * (10.0 ** (mel_pts / 2595.0) - 1.0)
+    dhz = hz[1:] - hz[:-1]
+    slope = hz.unsqueeze(0) - freqs.unsqueeze(1)
+    lower = (-1.0 * slope[:, :-2]) / dhz[:-1]
+    upper = slope[:, 2:] / dhz[1:]
+    return torch.max(torch.zeros(1), torch.min(lower, upper))
+
+
+class MelFeatPlan:
+    """Owns an `mst_plan` (device tables for one STFT/mel configuration) and a cached workspace."""
+
+    def __init__(self, sample_rate, n_fft, hop_length, n_mels, detailed_bins=0, window=None, fb=None):
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.window = (hann_window(n_fft) if window is None else window).detach().float().cpu().contiguous()
+        self.fb = (melscale_fbanks_htk(n_fft // 2 + 1, n_mels, sample_rate) if fb is None else fb)
+        self.fb = self.fb.detach().float().cpu().contiguous()
+        h = C.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.mst_plan_create(C.byref(h), sample_rate, n_fft, hop_length, n_mels,
+                                     C.c_void_p(self.window.data_ptr()), C.c_void_p(self.fb.data_ptr()),
+                                     int(detailed_bins)), "mst_plan_create")
+        self._h = h
+        self.feature_dim = L.mst_plan_feature_dim(h)
+        self._ws = None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().mst_plan_destroy(h)
+            except Exception:
+                pass
+
+    def frames(self, T: int) -> int:
+        return 1 + T // self.hop_length
+
+    def _workspace(self, B, T, device):
+        need = _lib.lib().mst_melfeat_workspace_bytes(self._h, B, T)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws, need
+
+    def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True):
+        """stems8 (B, 8, T) fp32 CUDA contiguous -> (logmel (B,8,M,F) | None, feats (B,Fd) | None)."""
+        if not stems8.is_cuda:
+            raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
+        x = stems8.contiguous().float()
+        B, ch, T = x.shape
+        assert ch == 8, "expected 8 channels (4 stems x stereo)"
+        F = self.frames(T)
+        logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=x.device) if want_logmel else None
+        feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=x.device) if want_feats else None
+        ws, need = self._workspace(B, T, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mst_melfeat_forward(self._h, _lib.dptr(x), B, T, _lib.dptr(logmel), _lib.dptr(feats),
+                                                      _lib.dptr(ws), need, _lib.stream_ptr(x.device)),
+                       "mst_melfeat_forward")
+        return logmel, feats
+
+
+def stems_to_tensor(stems_dict) -> torch.Tensor:
+    """{stem: (2,T) | (B,2,T)} -> (B, 8, T) in channel order vL,vR,bL,bR,dL,dR,oL,oR."""
+    parts = [stems_dict[s] for s in STEMS]
+    if parts[0].dim() == 2:
+        parts = [p.unsqueeze(0) for p in parts]
+    return torch.cat(parts, dim=1)
+
+
+class _MelTransformView:
+    """Attribute surface of torchaudio.transforms.MelSpectrogram that reference callers touch
+    (`.spectrogram.window.device`, `.to()`; src/mixing_utils.py:155-156,274-275)."""
+
+    class _Ns:
+        pass
+
+    def __init__(self, window, fb):
+        self.spectrogram = self._Ns()
+        self.spectrogram.window = window
+        self.mel_scale = self._Ns()
+        self.mel_scale.fb = fb
+
+    def to(self, device):
+        self.spectrogram.window = self.spectrogram.window.to(device)
+        self.mel_scale.fb = self.mel_scale.fb.to(device)
+        return self
+
+
+class MixingFeatureExtractor:
+    """Extract interpretable mixing features from audio stems (reference src/mixing_utils.py:16-357)."""
+
+    def __init__(self, sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128, use_detailed_spectral=False,
+                 n_spectral_bins=32):
+        self.sr = sample_rate
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.n_mels = n_mels
+        self.use_detailed_spectral = use_detailed_spectral
+        self.n_spectral_bins = n_spectral_bins
+        self._plan = None
+        self.mel_transform = _MelTransformView(hann_window(n_fft), melscale_fbanks_htk(n_fft // 2 + 1, n_mels,
+                                                                                      sample_rate))
+
+    def get_feature_dim(self):
+        spectral = 5 if not self.use_detailed_spectral else (self.n_spectral_bins + 2)
+        return 4 * (6 + spectral + 3) + 4 + 4
+
+    def plan(self) -> MelFeatPlan:
+        if self._plan is None:
+            self._plan = MelFeatPlan(self.sr, self.n_fft, self.hop_length, self.n_mels,
+                                     self.n_spectral_bins if self.use_detailed_spectral else 0)
+        return self._plan
+
+    def features_and_logmel(self, stems_dict):
+        """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F))."""
+        lm, f = self.plan().forward(stems_to_tensor(stems_dict), True, True)
+        return f, lm
+
+    def extract_all_features(self, stems_dict):
+        """stems_dict {stem: (2,T)} -> (feature_dim,)  [reference]; {stem: (B,2,T)} -> (B, feature_dim)."""
+        batched = next(iter(stems_dict.values())).dim() == 3
+        _, f = self.plan().forward(stems_to_tensor(stems_dict), False, True)
+        return f if batched else f[0]
+
+    # ---- per-group views of the fused feature vector (reference public sub-methods)
+    def _single(self, audio):
+        z = torch.zeros_like(audio)
+        f = self.extract_all_features({"vocals": audio, "bass": z, "drums": z, "other": z})
+        sd = 5 if not self.use_detailed_spectral else self.n_spectral_bins + 2
+        return f, 3 * (10 + sd) + 4, sd
+
+    def extract_dynamics(self, audio):
+        f, o, _ = self._single(audio)
+        return f[o:o + 6]
+
+    def extract_spectral(self, audio):
+        f, o, sd = self._single(audio)
+        return f[o + 7:o + 7 + sd]
+
+    def extract_stereo(self, audio):
+        f, o, sd = self._single(audio)
+        return f[o + 7 + sd:o + 10 + sd]
+
+    def compute_loudness(self, audio):
+        f, o, _ = self._single(audio)
+        return f[o + 4]
+
+    def extract_masking(self, stems_dict):
+        f = self.extract_all_features(stems_dict)
+        sd = 5 if not self.use_detailed_spectral else self.n_spectral_bins + 2
+        return f[2 * (10 + sd):2 * (10 + sd) + 4]

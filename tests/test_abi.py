@@ -1,0 +1,66 @@
+"""CPU: libmst.so builds, loads, and exports every symbol include/mst.h declares (no compute calls)."""
+import os
+import re
+
+import pytest
+
+import cases  # noqa: F401  (sys.path setup)
+from mst_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "mst.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mst_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(built):
+    decl = declared_symbols()
+    assert decl, "no declarations parsed"
+    assert set(decl) == set(_lib.SYMBOLS), (set(decl) ^ set(_lib.SYMBOLS))
+    for name in decl:
+        assert hasattr(built, name), f"libmst.so does not export {name}"
+
+
+def test_version_and_error_string(built):
+    assert built.mst_version() == 1
+    assert isinstance(built.mst_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(_lib.EncoderConfig) == 9 * 4
+    assert C.sizeof(_lib.EncoderWeights) == 24 * C.sizeof(C.c_void_p)
+    assert C.sizeof(_lib.AugStem) == 16 + 18 * 8
+    assert C.sizeof(_lib.AugClip) == 4 * C.sizeof(_lib.AugStem) + 8
+
+
+def test_product_refuses_cpu_tensors():
+    """The product path must fail loudly without the GPU (no CPU fallback)."""
+    import torch
+    from mst_amd.mixing_utils import MixingFeatureExtractor
+    fe = MixingFeatureExtractor()
+    assert fe.get_feature_dim() == 64
+    assert MixingFeatureExtractor(use_detailed_spectral=True, n_spectral_bins=32).get_feature_dim() == 180
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        fe.extract_all_features({k: torch.zeros(2, 4096) for k in ("vocals", "bass", "drums", "other")})
+
+
+def test_host_filterbank_matches_golden():
+    import numpy as np
+    from mst_amd.mixing_utils import hann_window, melscale_fbanks_htk
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fbanks.npz"))
+    for n_fft, n_mels in ((1024, 128), (1024, 256), (2048, 80)):
+        assert np.array_equal(melscale_fbanks_htk(n_fft // 2 + 1, n_mels, 44100).numpy(), g[f"fb_{n_fft}_{n_mels}"])
+        assert np.array_equal(hann_window(n_fft).numpy(), g[f"win_{n_fft}"])
