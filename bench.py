@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Contract benchmark: triplets/s of the contrastive data-path hot path on N MI355X (one process per GPU).
+
+A "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+    24 triplets = 72 clips of 10 s / 44.1 kHz / 4 stems x stereo per GPU  (BASELINE.json configs[1]/[2])
+    stage A  HIP  waveform -> STFT -> 128-mel -> log-mel (B,8,128,1723) + 64-d mixing features
+    stage B       FiLM MLP + 11 x band-split Conv/BN/FiLM/ReLU/MaxPool x2 + attention pooling -> (B,768)
+                  ("hip": libmst.so fp32-MFMA kernels = configs[2];  "torch": PyTorch-ROCm ops = configs[1])
+    exchange      all-gather of embeddings + labels over RCCL (N>1) and InfoNCE on the gathered batch
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement), with `roofline` for the
+dominant hand-written kernel (HIP-event timed inside the timed region) and `cpu_baseline` (the CPU oracle
+timed on the host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
+MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--triplets", type=int, default=24, help="triplets per GPU per step (3 clips each)")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--encoder", choices=["auto", "hip", "torch"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def hip_encoder_available():
+    from mst_amd import _lib
+    import ctypes as C
+    h = C.c_void_p()
+    rc = _lib.lib().mst_encoder_create(C.byref(h), None, None)
+    return b"not implemented" not in (_lib.lib().mst_last_error() or b"")
+
+
+def cpu_baseline(model_sd, cfg, T, budget_s=20.0):
+    """CPU oracle (the parity-pinned restatement of the reference path) on the host cores, bounded sample."""
+    from oracle import encoder as oenc
+    from oracle import features as ofeat
+    from mst_amd.synth import synth_batch
+    # the GPU box gives a 1-GPU job a share of 16 host cores; os.cpu_count() reports the whole machine
+    ncpu = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(ncpu)
+    sd = {k: v.detach().cpu() for k, v in model_sd.items()}
+    B = 3  # one triplet per iteration
+    x = synth_batch(B, T)
+    clips, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        oenc.encoder_forward(sd, x[:1], ofeat.extract_all_features(x[:1]))  # warm-up (thread pools, fft plans)
+        t0 = time.perf_counter()
+        while True:
+            f = ofeat.extract_all_features(x)          # reference: computed in the Dataset worker
+            oenc.encoder_forward(sd, x, f)             # reference: MixingStyleEncoder.forward (mel again + CNN)
+            clips += B
+            el = time.perf_counter() - t0
+            if el > budget_s or clips >= 30:
+                break
+    return {"value": round(clips / 3.0 / el, 4), "unit": "triplets/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{clips} clips ({clips // 3} triplets) of {T / 44100:.0f} s, oracle/ "
+            f"features+mel+encoder fwd, torch-CPU fp32, {el:.1f} s wall"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from mst_amd.loss import InfoNCELoss
+    from mst_amd.mixing_utils import MixingFeatureExtractor
+    from mst_amd.model import MixingStyleEncoder
+    from mst_amd.synth import synth_batch
+
+    sr, n_fft, hop, n_mels = 44100, 1024, 256, 128
+    T = int(a.seconds * sr)
+    B = 3 * a.triplets
+    backend = a.encoder if a.encoder != "auto" else ("hip" if hip_encoder_available() else "torch")
+
+    torch.manual_seed(42)
+    model = MixingStyleEncoder(sr, n_fft, hop, n_mels, 20, 10, 8, 768, feature_dim=64, encoder_backend=backend)
+    with torch.no_grad():  # FiLM gammas ~ 1 (trained-looking) so activations stay O(1); random-init otherwise
+        b = model.film_encoder.film_head.bias
+        for i in range(model.audio_encoder.n_subbands):
+            b[i * 192:i * 192 + 32] += 1.0
+            b[i * 192 + 64:i * 192 + 128] += 1.0
+    model = model.to(dev).eval()
+    fe = MixingFeatureExtractor(sr, n_fft, hop, n_mels)
+    crit = InfoNCELoss(0.1, gather=world > 1)
+
+    x = synth_batch(B, T, sr, device=dev, first_clip=rank * B)   # resident in HBM before timing
+    stems = {s: x[:, 2 * i:2 * i + 2] for i, s in enumerate(("vocals", "bass", "drums", "other"))}
+    labels = (torch.arange(B, device=dev) // 3) + rank * a.triplets  # 3 clips of a triplet share a song id
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    marks = []
+
+    def step(timed):
+        with torch.no_grad():
+            e0, e1, e2 = (ev(), ev(), ev()) if timed else (None, None, None)
+            if timed:
+                e0.record()
+            feats, logmel = fe.features_and_logmel(stems)
+            if timed:
+                e1.record()
+            emb = model.forward_from_logmel(logmel, feats)
+            if timed:
+                e2.record()
+                marks.append((e0, e1, e2))
+            return crit(emb, labels)
+
+    for _ in range(a.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = t.item()
+
+    msA = sum(m[0].elapsed_time(m[1]) for m in marks) / len(marks)
+    msB = sum(m[1].elapsed_time(m[2]) for m in marks) / len(marks)
+    if rank == 0:
+        n_frames = 1 + T // hop
+        bytes_a = B * (8 * T * 4 + 8 * n_mels * n_frames * 4 + 64 * 4)      # 21,169,664 B/clip
+        flops_b = B * 17.17e9 * (T / 441000.0)                               # 17.17 GFLOP/clip
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if backend == "hip":
+            roof = {"kernel": "encoder stage B (conv1+conv2 fp32 MFMA implicit GEMM, FiLM MLP, attention pool)",
+                    "bound": "mfma", "achieved": round(flops_b / (msB * 1e-3) / 1e12, 3), "peak": MFMA_F32_PEAK_TF,
+                    "unit": "TFLOP/s"}
+            key = "stage_b"
+        else:
+            roof = {"kernel": "melfeat_kernel<1024,2> (+finalize): STFT->mel->log-mel+feature partials",
+                    "bound": "hbm", "achieved": round(bytes_a / (msA * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s"}
+            key = "stage_a"
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
+        roof["traffic"] = traffic
+        roof["stage_a_ms"] = round(msA, 4)
+        roof["stage_a_gbs"] = round(bytes_a / (msA * 1e-3) / 1e9, 1)
+        roof["stage_a_hbm_frac"] = round(bytes_a / (msA * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roof["stage_b_ms"] = round(msB, 4)
+        roof["stage_b_tflops"] = round(flops_b / (msB * 1e-3) / 1e12, 3)
+        out = {
+            "metric": "triplets/sec (10 s @ 44.1 kHz, 4-stem, bs=24)",
+            "value": round(world * a.triplets * a.steps / el, 3),
+            "unit": "triplets/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": ("configs[2]" if backend == "hip" else "configs[1]") +
+                       f": synthetic {a.seconds:.0f} s stereo 4-stem clips, {a.triplets} triplets = {B} clips per GPU, "
+                       f"HIP STFT+{n_mels}-mel+64-d features, encoder fwd in " +
+                       ("HIP (fp32 MFMA)" if backend == "hip" else "PyTorch-ROCm") +
+                       ", InfoNCE on all-gathered embeddings",
+                       "clips_per_gpu": B, "clip_samples": T, "n_fft": n_fft, "hop": hop, "n_mels": n_mels,
+                       "encoder_backend": backend, "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model.state_dict(), None, T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

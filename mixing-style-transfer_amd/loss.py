@@ -1,0 +1,69 @@
+"""InfoNCE loss with the reference semantics (src/loss.py:10-136), vectorised (no per-anchor host syncs) and
+sharded: with torch.distributed initialised, embeddings and labels are all-gathered over RCCL/xGMI so every
+rank scores its local anchors against the global batch."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def gather_embeddings(emb: torch.Tensor, labels: torch.Tensor):
+    """All-gather (N_local, D) fp32 embeddings + (N_local,) int64 labels -> global tensors, rank order.
+    Gradient flows to the local slice only (the other slices are constants on this rank)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return emb, labels, 0
+    ws, rank = dist.get_world_size(), dist.get_rank()
+    n = emb.shape[0]
+    all_e = torch.empty(ws * n, emb.shape[1], dtype=emb.dtype, device=emb.device)
+    all_l = torch.empty(ws * n, dtype=labels.dtype, device=labels.device)
+    dist.all_gather_into_tensor(all_e, emb.detach().contiguous())
+    dist.all_gather_into_tensor(all_l, labels.contiguous())
+    if emb.requires_grad:
+        all_e = torch.cat([all_e[:rank * n], emb, all_e[(rank + 1) * n:]], 0)
+    return all_e, all_l, rank * n
+
+
+def info_nce_rows(all_emb, all_labels, row0, rows, temperature):
+    """Sum of -log(pos/(pos+neg+1e-8)) over local anchors [row0,row0+rows) that have a positive, and their count."""
+    e = F.normalize(all_emb, dim=1)
+    sim = e[row0:row0 + rows] @ e.T / temperature            # (rows, N)
+    lab = all_labels
+    same = lab[row0:row0 + rows, None] == lab[None, :]
+    self_mask = torch.zeros_like(same)
+    self_mask[torch.arange(rows, device=sim.device), torch.arange(row0, row0 + rows, device=sim.device)] = True
+    ex = torch.exp(sim - sim.max(dim=1, keepdim=True)[0])
+    pos = (ex * (same & ~self_mask)).sum(1)
+    neg = (ex * (~same)).sum(1)
+    keep = pos > 0
+    li = -torch.log(pos / (pos + neg + 1e-8))
+    return torch.where(keep, li, torch.zeros_like(li)).sum(), keep.sum()
+
+
+class InfoNCELoss(nn.Module):
+    """Drop-in for reference InfoNCELoss(temperature)(embeddings (N, D), song_labels (N,)) -> scalar."""
+
+    def __init__(self, temperature=0.1, gather=False):
+        super().__init__()
+        self.temperature = temperature
+        self.gather = gather
+
+    def forward(self, embeddings, song_labels):
+        if self.gather:
+            import torch.distributed as dist
+            all_e, all_l, row0 = gather_embeddings(embeddings, song_labels)
+            s, c = info_nce_rows(all_e, all_l, row0, embeddings.shape[0], self.temperature)
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                sc = torch.stack([s.detach(), c.to(s.dtype)])
+                dist.all_reduce(sc)
+                if sc[1].item() == 0:
+                    raise RuntimeError("No positive pairs found in batch!")
+                # mean over all valid anchors of the global batch; gradient of the local share
+                return s / sc[1] * dist.get_world_size() if s.requires_grad else sc[0] / sc[1]
+        else:
+            s, c = info_nce_rows(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
+        if c.item() == 0:
+            raise RuntimeError(
+                f"No positive pairs found in batch! Batch size: {embeddings.shape[0]}, "
+                f"Unique songs: {len(torch.unique(song_labels))}, "
+                f"This likely means each song only appears once in the batch.")
+        return s / c

@@ -1,0 +1,272 @@
+"""MI355X mirror of reference src/model.py: MelSpectrogramPreprocessor, BandSplitEncoder, MixingFeatureEncoder,
+MixingStyleEncoder (same constructor arguments, attributes and state_dict keys, so reference checkpoints load
+with strict=True and reference call sites -- train.py:253,299,410, validation_utils.py:101 -- work unchanged).
+
+Forward paths
+  * inference (`model.eval()` or `torch.no_grad()`): hand-written HIP kernels through libmst.so --
+    stage A (STFT -> mel -> log) and stage B (FiLM MLP, band-split conv stack, attention pooling).
+    This is the product path and the one every parity claim refers to.
+  * training with autograd (`model.train()` and grad enabled): stage A still runs in HIP (the waveform needs
+    no gradient); the encoder runs on PyTorch-ROCm ops so that autograd, train-mode BatchNorm statistics and
+    Dropout behave as in the reference.  HIP backward kernels are the next row of SURVEY.md section 8(f).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .mixing_utils import STEMS, MelFeatPlan, hann_window, melscale_fbanks_htk, stems_to_tensor
+
+
+class _Buf(nn.Module):
+    def __init__(self, name, value):
+        super().__init__()
+        self.register_buffer(name, value)
+
+
+class _MelTransform(nn.Module):
+    """Holds torchaudio's persistent buffers under their checkpoint names
+    (`mel_transform.spectrogram.window`, `mel_transform.mel_scale.fb`)."""
+
+    def __init__(self, sample_rate, n_fft, n_mels):
+        super().__init__()
+        self.spectrogram = _Buf("window", hann_window(n_fft))
+        self.mel_scale = _Buf("fb", melscale_fbanks_htk(n_fft // 2 + 1, n_mels, sample_rate))
+
+
+class MelSpectrogramPreprocessor(nn.Module):
+    """Dict of 4 stems, each (B, 2, T) -> log-mel (B, 8, n_mels, frames).  reference src/model.py:17-67"""
+
+    def __init__(self, sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128):
+        super().__init__()
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.mel_transform = _MelTransform(sample_rate, n_fft, n_mels)
+        self._plan = None
+
+    def plan(self) -> MelFeatPlan:
+        if self._plan is None:  # built from the module's own buffers, so a loaded checkpoint's tables are honoured
+            self._plan = MelFeatPlan(self.sample_rate, self.n_fft, self.hop_length, self.n_mels, 0,
+                                     self.mel_transform.spectrogram.window, self.mel_transform.mel_scale.fb)
+        return self._plan
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._plan = None
+
+    def forward(self, stems_dict):
+        lm, _ = self.plan().forward(stems_to_tensor(stems_dict), True, False)
+        return lm
+
+
+class FiLMLayer(nn.Module):
+    def __init__(self, num_features):
+        super().__init__()
+        self.num_features = num_features
+
+    def forward(self, x, gamma, beta):
+        return gamma[:, :, None, None] * x + beta[:, :, None, None]
+
+
+class SubSpectrogramCNN(nn.Module):
+    """One band-split branch (reference src/model.py:97-157); parameters only -- the eval forward of all branches
+    runs fused in the HIP encoder."""
+
+    def __init__(self, split_size, channels, out_channels=64):
+        super().__init__()
+        self.split_size, self.channels, self.out_channels = split_size, channels, out_channels
+        sub = max(1, split_size // 10)
+        self.conv1 = nn.Conv2d(channels, 32, kernel_size=7, padding=3)
+        self.bn1 = nn.BatchNorm2d(32)
+        self.film1 = FiLMLayer(32)
+        self.pool1 = nn.MaxPool2d((sub, 5))
+        self.dropout1 = nn.Dropout(0.3)
+        self.conv2 = nn.Conv2d(32, out_channels, kernel_size=7, padding=3)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.film2 = FiLMLayer(out_channels)
+        self.pool2 = nn.MaxPool2d((4, 4))
+        self.dropout2 = nn.Dropout(0.3)
+
+    def forward(self, x, gamma1=None, beta1=None, gamma2=None, beta2=None):
+        for conv, bn, film, pool, drop, g, b in ((self.conv1, self.bn1, self.film1, self.pool1, self.dropout1, gamma1,
+                                                  beta1), (self.conv2, self.bn2, self.film2, self.pool2, self.dropout2,
+                                                           gamma2, beta2)):
+            x = bn(conv(x))
+            if g is not None and b is not None:
+                x = film(x, g, b)
+            x = drop(pool(F.relu(x)))
+        return x
+
+
+class AttentionPooling(nn.Module):
+    """reference src/model.py:160-211"""
+
+    def __init__(self, input_dim, hidden_dim=128, output_dim=768):
+        super().__init__()
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.attention = nn.Sequential(nn.Linear(input_dim, hidden_dim), nn.Tanh(), nn.Linear(hidden_dim, 1))
+        self.projection = nn.Sequential(nn.Linear(input_dim, output_dim), nn.ReLU(), nn.Dropout(0.3))
+
+    def forward(self, x):
+        xt = x.transpose(1, 2)
+        w = F.softmax(self.attention(xt), dim=1)
+        return self.projection((xt * w).sum(dim=1))
+
+
+def count_subbands(n_mels, split_size, overlap):
+    return len(range(0, n_mels - split_size + 1, overlap))
+
+
+class BandSplitEncoder(nn.Module):
+    """reference src/model.py:214-382"""
+
+    def __init__(self, sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128, split_size=20, overlap=10,
+                 channels=8, embed_dim=768, cnn_out_channels=64):
+        super().__init__()
+        if channels != 8 or cnn_out_channels != 64:
+            raise ValueError("the HIP encoder is built for 8 input channels (4 stems x stereo) and 64 CNN outputs")
+        self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.split_size, self.overlap, self.channels, self.cnn_out_channels = split_size, overlap, channels, 64
+        self.mel_preprocessor = MelSpectrogramPreprocessor(sample_rate, n_fft, hop_length, n_mels)
+        self.n_subbands = count_subbands(n_mels, split_size, overlap)
+        self.subnet_cnns = nn.ModuleList([SubSpectrogramCNN(split_size, channels, 64) for _ in range(self.n_subbands)])
+        sub = max(1, split_size // 10)
+        frames_10s = int(10.0 * sample_rate) // hop_length + 1
+        self.freq_dim = (split_size // sub) // 4
+        self.time_dim = (frames_10s // 5) // 4
+        self.attention_pooling = AttentionPooling(64 * self.n_subbands * self.freq_dim, hidden_dim=256,
+                                                  output_dim=embed_dim)
+
+    def forward_from_logmel(self, x, film_params=None):
+        """PyTorch-ROCm op path (autograd-capable).  x (B, 8, n_mels, frames)."""
+        outs = []
+        for i, cnn in enumerate(self.subnet_cnns):
+            fp = film_params or {}
+            outs.append(cnn(x[:, :, i * self.overlap:i * self.overlap + self.split_size, :], fp.get(f"gamma1_{i}"),
+                            fp.get(f"beta1_{i}"), fp.get(f"gamma2_{i}"), fp.get(f"beta2_{i}")))
+        y = torch.cat(outs, dim=1)
+        return self.attention_pooling(y.reshape(y.shape[0], y.shape[1] * y.shape[2], y.shape[3]))
+
+    def forward(self, stems_dict, film_params=None):
+        return self.forward_from_logmel(self.mel_preprocessor(stems_dict), film_params)
+
+
+class MixingFeatureEncoder(nn.Module):
+    """reference src/model.py:385-464"""
+
+    def __init__(self, feature_dim, n_subbands, hidden_dim=256):
+        super().__init__()
+        self.feature_dim, self.n_subbands = feature_dim, n_subbands
+        self.feature_mlp = nn.Sequential(nn.Linear(feature_dim, hidden_dim), nn.ReLU(), nn.Dropout(0.2),
+                                         nn.Linear(hidden_dim, hidden_dim), nn.ReLU())
+        self.film_head = nn.Linear(hidden_dim, n_subbands * 192)
+
+    def forward(self, features):
+        flat = self.film_head(self.feature_mlp(features))
+        out = {}
+        for i in range(self.n_subbands):
+            g1, b1, g2, b2 = torch.split(flat[:, i * 192:(i + 1) * 192], [32, 32, 64, 64], dim=1)
+            out[f"gamma1_{i}"], out[f"beta1_{i}"], out[f"gamma2_{i}"], out[f"beta2_{i}"] = g1, b1, g2, b2
+        return out
+
+
+class HipEncoder:
+    """Owns an `mst_encoder` handle built from a module's current parameters (eval-mode forward in HIP)."""
+
+    def __init__(self, model: "MixingStyleEncoder"):
+        ae, fe = model.audio_encoder, model.film_encoder
+        cpu = lambda t: t.detach().float().cpu().contiguous()
+        cat = lambda name: cpu(torch.stack([getattr(getattr(c, name.split(".")[0]), name.split(".")[1])
+                                            for c in ae.subnet_cnns], 0))
+        self._keep = dict(
+            conv1_w=cat("conv1.weight"), conv1_b=cat("conv1.bias"), bn1_w=cat("bn1.weight"), bn1_b=cat("bn1.bias"),
+            bn1_mean=cat("bn1.running_mean"), bn1_var=cat("bn1.running_var"),
+            conv2_w=cat("conv2.weight"), conv2_b=cat("conv2.bias"), bn2_w=cat("bn2.weight"), bn2_b=cat("bn2.bias"),
+            bn2_mean=cat("bn2.running_mean"), bn2_var=cat("bn2.running_var"),
+            mlp0_w=cpu(fe.feature_mlp[0].weight), mlp0_b=cpu(fe.feature_mlp[0].bias),
+            mlp3_w=cpu(fe.feature_mlp[3].weight), mlp3_b=cpu(fe.feature_mlp[3].bias),
+            head_w=cpu(fe.film_head.weight), head_b=cpu(fe.film_head.bias),
+            att0_w=cpu(ae.attention_pooling.attention[0].weight), att0_b=cpu(ae.attention_pooling.attention[0].bias),
+            att2_w=cpu(ae.attention_pooling.attention[2].weight), att2_b=cpu(ae.attention_pooling.attention[2].bias),
+            proj_w=cpu(ae.attention_pooling.projection[0].weight), proj_b=cpu(ae.attention_pooling.projection[0].bias))
+        w = _lib.EncoderWeights(**{k: v.data_ptr() for k, v in self._keep.items()})
+        self.cfg = _lib.EncoderConfig(ae.n_mels, ae.split_size, ae.overlap, ae.n_subbands, fe.feature_dim,
+                                      ae.attention_pooling.output_dim, fe.feature_mlp[0].out_features,
+                                      ae.attention_pooling.attention[0].out_features, float(ae.subnet_cnns[0].bn1.eps))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mst_encoder_create(C.byref(h), C.byref(self.cfg), C.byref(w)), "mst_encoder_create")
+        self._h = h
+        self._ws = None
+        self.embed_dim = ae.attention_pooling.output_dim
+        self.n_sub, self.split, self.freq_dim = ae.n_subbands, ae.split_size, ae.freq_dim
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                _lib.lib().mst_encoder_destroy(h)
+            except Exception:
+                pass
+
+    def forward(self, logmel, feats, taps=False):
+        B, _, M, Fr = logmel.shape
+        L = _lib.lib()
+        need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=logmel.device)
+        emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=logmel.device)
+        t, out = None, {}
+        if taps:
+            sub = max(1, self.split // 10)
+            H1, W1 = self.split // sub, Fr // 5
+            out = dict(film=torch.empty(B, self.n_sub * 192, device=logmel.device),
+                       pool1=torch.empty(B, self.n_sub, 32, H1, W1, device=logmel.device),
+                       pool_in=torch.empty(B, 64 * self.n_sub * self.freq_dim, W1 // 4, device=logmel.device))
+            t = C.byref(_lib.EncoderTaps(out["film"].data_ptr(), out["pool1"].data_ptr(), out["pool_in"].data_ptr()))
+        with torch.cuda.device(logmel.device):
+            _lib.check(L.mst_encoder_forward(self._h, _lib.dptr(logmel), Fr, _lib.dptr(feats.contiguous().float()), B,
+                                             _lib.dptr(emb), t, _lib.dptr(self._ws), need,
+                                             _lib.stream_ptr(logmel.device)), "mst_encoder_forward")
+        return (emb, out) if taps else emb
+
+
+class MixingStyleEncoder(nn.Module):
+    """reference src/model.py:467-542.  `encoder_backend`: "hip" (default; eval/no-grad forward in libmst.so) or
+    "torch" (PyTorch-ROCm ops for stage B; stage A stays HIP) -- BASELINE.json configs[2] vs configs[1]."""
+
+    def __init__(self, sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128, split_size=20, overlap=10,
+                 channels=8, embed_dim=768, feature_dim=256, encoder_backend="hip"):
+        super().__init__()
+        self.audio_encoder = BandSplitEncoder(sample_rate, n_fft, hop_length, n_mels, split_size, overlap, channels,
+                                              embed_dim)
+        self.film_encoder = MixingFeatureEncoder(feature_dim, self.audio_encoder.n_subbands)
+        self.encoder_backend = encoder_backend
+        self._hip = None
+        self._hip_version = None
+
+    def _params_version(self):
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+
+    def hip_encoder(self) -> HipEncoder:
+        v = self._params_version()
+        if self._hip is None or v != self._hip_version:  # weights changed (optimizer step / load_state_dict)
+            self._hip, self._hip_version = HipEncoder(self), v
+        return self._hip
+
+    def _needs_autograd(self, mixing_features):
+        return torch.is_grad_enabled() and (self.training or mixing_features.requires_grad) and \
+            any(p.requires_grad for p in self.parameters())
+
+    def forward_from_logmel(self, logmel, mixing_features):
+        if self.encoder_backend == "hip" and not self._needs_autograd(mixing_features):
+            if self.training:
+                raise RuntimeError("HIP encoder forward implements eval-mode BatchNorm/Dropout; call model.eval() "
+                                   "or enable grad for the PyTorch-ROCm training path")
+            return self.hip_encoder().forward(logmel, mixing_features)
+        return self.audio_encoder.forward_from_logmel(logmel, self.film_encoder(mixing_features))
+
+    def forward(self, stems_dict, mixing_features):
+        with torch.no_grad():
+            logmel = self.audio_encoder.mel_preprocessor(stems_dict)
+        return self.forward_from_logmel(logmel, mixing_features)
