@@ -47,7 +47,7 @@ def hip_encoder_available():
     return b"not implemented" not in (_lib.lib().mst_last_error() or b"")
 
 
-def cpu_baseline(model_sd, cfg, T, budget_s=20.0):
+def cpu_baseline(model_sd, cfg, T, budget_s=15.0):
     """CPU oracle (the parity-pinned restatement of the reference path) on the host cores, bounded sample."""
     from oracle import encoder as oenc
     from oracle import features as ofeat
@@ -67,7 +67,7 @@ def cpu_baseline(model_sd, cfg, T, budget_s=20.0):
             oenc.encoder_forward(sd, x, f)             # reference: MixingStyleEncoder.forward (mel again + CNN)
             clips += B
             el = time.perf_counter() - t0
-            if el > budget_s or clips >= 30:
+            if el > budget_s or clips >= 150:
                 break
     return {"value": round(clips / 3.0 / el, 4), "unit": "triplets/s", "cores": torch.get_num_threads(),
             "kind": "port", "sample": f"{clips} clips ({clips // 3} triplets) of {T / 44100:.0f} s, oracle/ "
@@ -112,7 +112,11 @@ def main():
     stems = {s: x[:, 2 * i:2 * i + 2] for i, s in enumerate(("vocals", "bass", "drums", "other"))}
     labels = (torch.arange(B, device=dev) // 3) + rank * a.triplets  # 3 clips of a triplet share a song id
 
-    ev = lambda: torch.cuda.Event(enable_timing=True)
+    def ev():
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()   # materialise the hipEvent_t so the raw handle can be passed through the C ABI
+        return e
+
     marks = []
 
     def step(timed):
@@ -123,10 +127,15 @@ def main():
             feats, logmel = fe.features_and_logmel(stems)
             if timed:
                 e1.record()
-            emb = model.forward_from_logmel(logmel, feats)
+            if backend == "hip":
+                kev = [ev() for _ in range(6)] if timed else None
+                emb = model.hip_encoder().forward(logmel, feats, events=kev)
+            else:
+                kev = None
+                emb = model.forward_from_logmel(logmel, feats)
             if timed:
                 e2.record()
-                marks.append((e0, e1, e2))
+                marks.append((e0, e1, e2, kev))
             return crit(emb, labels)
 
     for _ in range(a.warmup):
@@ -155,15 +164,18 @@ def main():
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if backend == "hip":
-            roof = {"kernel": "encoder stage B (conv1+conv2 fp32 MFMA implicit GEMM, FiLM MLP, attention pool)",
-                    "bound": "mfma", "achieved": round(flops_b / (msB * 1e-3) / 1e12, 3), "peak": MFMA_F32_PEAK_TF,
+            kms = [sum(m[3][i].elapsed_time(m[3][i + 1]) for m in marks) / len(marks) for i in range(5)]
+            W1 = n_frames // 5
+            flops_c1 = B * 11 * 2.0 * 32 * 392 * 20 * n_frames            # 9.510 GFLOP/clip, all needed
+            flops_c2 = B * 11 * 2.0 * 64 * 1568 * 8 * W1                   # executed: rows 0..7 of 10 (rows 8,9 never
+            #                                                                reach MaxPool(4,4)); reference computes 10
+            roof = {"kernel": "conv_kernel<1,2>: Conv7x7(8->32)+BN+FiLM+ReLU+MaxPool(2,5), fp32 MFMA 16x16x4 implicit GEMM",
+                    "bound": "mfma", "achieved": round(flops_c1 / (kms[1] * 1e-3) / 1e12, 3), "peak": MFMA_F32_PEAK_TF,
                     "unit": "TFLOP/s"}
-            key = "stage_b"
-        else:
-            roof = {"kernel": "melfeat_kernel<1024,2> (+finalize): STFT->mel->log-mel+feature partials",
-                    "bound": "hbm", "achieved": round(bytes_a / (msA * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s"}
-            key = "stage_a"
+            roof["kernels_ms"] = {"film_mlp": round(kms[0], 4), "conv1": round(kms[1], 4), "conv2": round(kms[2], 4),
+                                  "attn_scores": round(kms[3], 4), "attn_pool_proj": round(kms[4], 4)}
+            roof["conv2_tflops_executed"] = round(flops_c2 / (kms[2] * 1e-3) / 1e12, 3)
+            key = "conv1"
         if os.path.exists(tp):
             try:
                 traffic = json.load(open(tp)).get(key, {}).get("hbm_bytes_per_launch")

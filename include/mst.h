@@ -110,6 +110,8 @@ typedef struct mst_encoder_taps {
   float* film;     /* dev [B][n_sub*192]                      */
   float* pool1;    /* dev [B][n_sub][32][H1][W1]              */
   float* pool_in;  /* dev [B][64*n_sub*freq_dim][W2]  (input of attention pooling) */
+  void* events[6]; /* optional hipEvent_t recorded on the stream: [0] start, [1] after FiLM MLP, [2] after conv1,
+                      [3] after conv2, [4] after attention scores, [5] end (per-kernel timing for bench.py) */
 } mst_encoder_taps;
 
 int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg,

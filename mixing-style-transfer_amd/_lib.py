@@ -36,7 +36,7 @@ class EncoderWeights(C.Structure):
 
 
 class EncoderTaps(C.Structure):
-    _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p)]
+    _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("events", C.c_void_p * 6)]
 
 
 class AugStem(C.Structure):

@@ -1,0 +1,631 @@
+// Stage B: FiLM MLP -> per-band [Conv7x7 + BN(eval) + FiLM + ReLU + MaxPool] x2 -> attention pooling -> projection.
+//
+// Replaces (reference barry-mir/mixing-style-transfer, eval mode): MixingFeatureEncoder.forward
+// src/model.py:410-464, SubSpectrogramCNN.forward :127-157 (looped over sub-bands :345-362), the concat/view
+// :332-367 and AttentionPooling.forward :187-211.
+//
+// Convolutions are implicit GEMMs on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32, a k-ordered fmaf
+// chain): rows = output positions, columns = output channels, K = (tap, input channel).  The row order inside
+// a wave tile is chosen so that every max-pool window lies in the accumulator registers of ONE lane: BN(eval),
+// FiLM, ReLU and the max-pool run in registers and only pooled activations reach HBM.
+//   * one workgroup = 8 waves (2 per SIMD), persistent over "sets" of 8 wave tiles of one sub-band;
+//   * weights stream through LDS in chunks of 4 input channels x 49 taps, pre-swizzled on the host into MFMA
+//     B-fragment order (one conflict-free ds_read_b32 per fragment);
+//   * each wave owns a private LDS patch (4 channels x (rows+6) x (cols+6)) of its tile: no inter-wave
+//     hand-off except the shared weight chunk (one barrier per chunk);
+//   * the next chunk (weights + patch) is prefetched into registers while the current one is on the MFMAs.
+#include "common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kConvThreads = 512;
+constexpr int kConvWaves = 8;
+
+// ------------------------------------------------------------------------------------------
+// FiLM MLP + folded per-(clip, band, channel) affine:  y = A * conv + C  with
+//   A = gamma * s,  C = gamma * t + beta,  s = bn_w / sqrt(var + eps),  t = s * (conv_b - mean) + bn_b
+// ------------------------------------------------------------------------------------------
+struct FilmParams {
+  const float* feats;
+  const float *w0t, *b0, *w3t, *b3, *hwt, *hb;  // transposed weights: [in][out]
+  const float *s1, *t1, *s2, *t2;               // [nsub][32], [nsub][64]
+  float* film;                                  // [B][nsub*192]
+  float2* aff1;                                 // [B][nsub][32]
+  float2* aff2;                                 // [B][nsub][64]
+  int Fd, H, nsub;
+};
+
+__global__ __launch_bounds__(256) void film_kernel(const FilmParams p) {
+  extern __shared__ float sm[];
+  float* f = sm;            // [Fd]
+  float* h1 = f + p.Fd;     // [H]
+  float* h2 = h1 + p.H;     // [H]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < p.Fd; i += 256) f[i] = p.feats[(size_t)b * p.Fd + i];
+  __syncthreads();
+  for (int j = tid; j < p.H; j += 256) {
+    float a = p.b0[j];
+    for (int i = 0; i < p.Fd; ++i) a = fmaf(p.w0t[(size_t)i * p.H + j], f[i], a);
+    h1[j] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  for (int j = tid; j < p.H; j += 256) {
+    float a = p.b3[j];
+    for (int i = 0; i < p.H; ++i) a = fmaf(p.w3t[(size_t)i * p.H + j], h1[i], a);
+    h2[j] = fmaxf(a, 0.f);
+  }
+  __syncthreads();
+  const int nout = p.nsub * 192;
+  float* film = p.film + (size_t)b * nout;
+  for (int o = tid; o < nout; o += 256) {
+    float a = p.hb[o];
+    for (int i = 0; i < p.H; ++i) a = fmaf(p.hwt[(size_t)i * nout + o], h2[i], a);
+    film[o] = a;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < p.nsub * 96; idx += 256) {
+    const int band = idx / 96, c = idx % 96;
+    if (c < 32) {
+      const float g = film[band * 192 + c], be = film[band * 192 + 32 + c];
+      p.aff1[((size_t)b * p.nsub + band) * 32 + c] = make_float2(g * p.s1[band * 32 + c], fmaf(g, p.t1[band * 32 + c], be));
+    } else {
+      const int c2 = c - 32;
+      const float g = film[band * 192 + 64 + c2], be = film[band * 192 + 128 + c2];
+      p.aff2[((size_t)b * p.nsub + band) * 64 + c2] =
+          make_float2(g * p.s2[band * 64 + c2], fmaf(g, p.t2[band * 64 + c2], be));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused conv + affine + ReLU + max-pool
+// ------------------------------------------------------------------------------------------
+template <int LAYER, int SUB>
+struct CC;
+template <int SUB>
+struct CC<1, SUB> {  // Conv2d(8 -> 32, 7x7, pad 3) + MaxPool2d((SUB, 5)),  SUB = max(1, split // 10) in {1, 2}
+  static constexpr int CIN = 8, COUT = 32, NCH = 2, MT = 5, NT = 2;
+  static constexpr int WIN = 5 * SUB;       // positions per pooling window
+  static constexpr int WPG = 20 / WIN;      // windows per 16-lane group (20 accumulator rows per group)
+  static constexpr int TROWS = SUB, TCOLS = 5 * 4 * WPG;  // input positions covered by one wave tile
+  static constexpr int PR = TROWS + 6, PC = TCOLS + 6;    // LDS patch (halo 3)
+  static constexpr int RL = PC <= 64 ? 64 : 128;          // loader row pitch (power of two >= PC)
+};
+template <int SUB>
+struct CC<2, SUB> {  // Conv2d(32 -> 64, 7x7, pad 3) + MaxPool2d((4, 4)); wave tile = 2x2 windows = 8x8 positions
+  static constexpr int CIN = 32, COUT = 64, NCH = 8, MT = 4, NT = 4;
+  static constexpr int WIN = 16, WPG = 1;
+  static constexpr int TROWS = 8, TCOLS = 8;
+  static constexpr int PR = 14, PC = 14;
+  static constexpr int RL = 16;
+};
+
+struct ConvParams {
+  const float* in;
+  const float* wfrag;  // [nsub][NCH][WCHP]   B fragments: [tap][nt][lane]
+  const float2* aff;   // [B][nsub][COUT]
+  float* out;
+  int B, nsub;
+  int in_rows, in_cols;       // valid extent of one band's input plane
+  int in_cstride;             // floats between input channels
+  int in_bandoff;             // floats between bands
+  long long in_clipstride;    // floats between clips
+  int out_rows, out_cols;     // pooled plane per (band, channel)
+  int tiles_r, tiles_c;       // wave tiles per (band, clip)
+  int sets_per_band;          // ceil(B * tiles_r * tiles_c / 8)
+};
+
+struct Tile {
+  int valid, clip, band, tr, tc;
+};
+
+template <int LAYER, int SUB>
+__global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) {
+  using C = CC<LAYER, SUB>;
+  constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
+  constexpr int WCH = 49 * NT * 64;                   // floats per weight chunk
+  constexpr int WCHP = (WCH + 255) / 256 * 256;       // padded chunk pitch
+  constexpr int PATCH = (4 * PR * PC + 3) / 4 * 4;    // floats per wave patch
+  constexpr int NWF = (WCH / 4 + kConvThreads - 1) / kConvThreads;  // float4 weight prefetches per thread
+  constexpr int NPF = (4 * PR * RL + 63) / 64;                       // patch prefetches per lane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* wbuf = smem;                                  // [2][WCHP]
+  float* pbuf = smem + 2 * WCHP + wave * PATCH;        // wave-private patch [4][PR][PC]
+
+  const int G = gridDim.x;
+  const int wg = mst::xcd_remap(blockIdx.x, G);
+  const int total_sets = p.nsub * p.sets_per_band;
+  const int my_sets = wg < total_sets ? (total_sets - wg + G - 1) / G : 0;
+  const int nq = my_sets * NCH;
+  const int tpb = p.tiles_r * p.tiles_c;
+
+  auto decode = [&](int q) {
+    const int s = wg + (q / NCH) * G;
+    Tile t;
+    t.band = s / p.sets_per_band;
+    const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
+    t.valid = idx < p.B * tpb;
+    t.clip = idx / tpb;
+    const int ti = idx - t.clip * tpb;
+    t.tc = ti / p.tiles_r;
+    t.tr = ti - t.tc * p.tiles_r;
+    return t;
+  };
+
+  // A-fragment base offsets (floats, inside the wave patch) for this lane: row i = lane & 15 of M-tile t maps to
+  // accumulator slot e = 4 t + (i & 3) of lane group g = i >> 2, i.e. window e / WIN, position e % WIN.
+  const int kq = lane >> 4, ai = lane & 15, ag = ai >> 2, areg = ai & 3;
+  int abase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    int dr, wc;
+    if constexpr (LAYER == 1) {
+      const int e = 4 * t + areg, wv = e / C::WIN, pos = e % C::WIN;
+      dr = pos / 5;
+      wc = 5 * (C::WPG * ag + wv) + pos % 5;
+    } else {
+      dr = 4 * (ag >> 1) + t;
+      wc = 4 * (ag & 1) + areg;
+    }
+    abase[t] = kq * (PR * PC) + dr * PC + wc;
+  }
+
+  float4 wreg[NWF];
+  float pf[NPF];
+  auto prefetch = [&](int q, const Tile& t) {
+    const int chunk = q % NCH;
+    const float4* wsrc = reinterpret_cast<const float4*>(p.wfrag + ((size_t)t.band * NCH + chunk) * WCHP);
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) {
+      const int k = tid + kConvThreads * i;
+      wreg[i] = (k < WCH / 4) ? wsrc[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int row0 = (LAYER == 1 ? C::TROWS * t.tr : 8 * t.tr) - 3;
+    const int col0 = C::TCOLS * t.tc - 3;
+    const float* src = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff +
+                       (size_t)(4 * chunk) * p.in_cstride;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = lane + 64 * i;
+      const int row = e / RL, col = e % RL;  // row = cc * PR + r
+      const int cc = row / PR, r = row - cc * PR;
+      const int rin = row0 + r, cin = col0 + col;
+      const bool ok = t.valid && row < 4 * PR && col < PC && rin >= 0 && rin < p.in_rows && cin >= 0 && cin < p.in_cols;
+      pf[i] = ok ? src[(size_t)cc * p.in_cstride + (size_t)rin * p.in_cols + cin] : 0.f;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  Tile cur{}, nxt{};
+  if (nq > 0) {
+    nxt = decode(0);
+    prefetch(0, nxt);
+  }
+  for (int q = 0; q < nq; ++q) {
+    float* wb = wbuf + (q & 1) * WCHP;
+    // stage the prefetched chunk into LDS
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) {
+      const int k = tid + kConvThreads * i;
+      if (k < WCH / 4) reinterpret_cast<float4*>(wb)[k] = wreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = lane + 64 * i;
+      const int row = e / RL, col = e % RL;
+      if (row < 4 * PR && col < PC) pbuf[row * PC + col] = pf[i];
+    }
+    __syncthreads();
+    cur = nxt;
+    if (q + 1 < nq) {
+      nxt = decode(q + 1);
+      prefetch(q + 1, nxt);
+    }
+    const int chunk = q % NCH;
+    if (chunk == 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // 49 taps x (MT A-fragments, NT B-fragments, MT*NT MFMAs)
+#pragma unroll
+    for (int tap = 0; tap < 49; ++tap) {
+      const int off = (tap / 7) * PC + (tap % 7);
+      float a[MT], b[NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[t] = pbuf[abase[t] + off];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[n] = wb[(tap * NT + n) * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n], acc[t][n], 0, 0, 0);
+    }
+    if (chunk == NCH - 1 && cur.valid) {
+      // epilogue: y = A*acc + C, ReLU, max over the window, all in this lane's registers
+      const int j = lane & 15, g = lane >> 4;
+      const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = n * 16 + j;
+        const float2 ac = aff[ch];
+        if constexpr (LAYER == 1) {
+#pragma unroll
+          for (int wv = 0; wv < C::WPG; ++wv) {
+            float m = 0.f;  // ReLU floor
+#pragma unroll
+            for (int pos = 0; pos < C::WIN; ++pos) {
+              const int e = wv * C::WIN + pos;
+              m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
+            }
+            const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
+            if (pc < p.out_cols)
+              p.out[((((size_t)cur.clip * p.nsub + cur.band) * C::COUT + ch) * p.out_rows + cur.tr) * p.out_cols + pc] = m;
+          }
+        } else {
+          float m = 0.f;
+#pragma unroll
+          for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaf(acc[t][n][r], ac.x, ac.y));
+          const int pr = 2 * cur.tr + (g >> 1), pc = 2 * cur.tc + (g & 1);
+          if (pr < p.out_rows && pc < p.out_cols)  // pool_in[clip][(band*64 + ch)*FD + pr][pc]
+            p.out[(((size_t)cur.clip * p.nsub + cur.band) * C::COUT + ch) * p.out_rows * p.out_cols +
+                  (size_t)pr * p.out_cols + pc] = m;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention scores: s[b][t] = w2 . tanh(W1 x[b,:,t] + b1) + b2      (model.py:198-200)
+// fp32-MFMA GEMM, one wave = 16 frames x all hidden units; W1 pre-swizzled into B-fragment order.
+// ------------------------------------------------------------------------------------------
+struct AttnParams {
+  const float* x;       // pool_in [B][C][W]
+  const float* w1frag;  // [C/4][NTA][64]
+  const float *b1, *w2;
+  float b2;
+  float* scores;        // [B][W]
+  int B, C, W, A;
+};
+
+template <int NTA>
+__global__ __launch_bounds__(256) void attn_scores_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mt = blockIdx.x * 4 + wave;
+  const int M = p.B * p.W;
+  if (mt * 16 >= M) return;
+  const int kq = lane >> 4, i = lane & 15;
+  const int m = mt * 16 + i;
+  const bool ok = m < M;
+  const int b = ok ? m / p.W : 0, t = ok ? m % p.W : 0;
+  const float* xa = p.x + ((size_t)b * p.C + kq) * p.W + t;
+  f32x4 acc[NTA];
+#pragma unroll
+  for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = p.C / 4;
+  const float* wf = p.w1frag + lane;
+  for (int s = 0; s < steps; ++s) {
+    const float a = ok ? xa[(size_t)s * 4 * p.W] : 0.f;
+#pragma unroll
+    for (int n = 0; n < NTA; ++n) {
+      const float bb = wf[((size_t)s * NTA + n) * 64];
+      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[n], 0, 0, 0);
+    }
+  }
+  // rows 4*kq + r of this M-tile live in lane group kq; columns n*16 + i
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float part = 0.f;
+#pragma unroll
+    for (int n = 0; n < NTA; ++n) {
+      const int h = n * 16 + i;
+      part = fmaf(p.w2[h], tanhf(acc[n][r] + p.b1[h]), part);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    const int mr = mt * 16 + 4 * kq + r;
+    if (i == 0 && mr < M) p.scores[mr] = part + p.b2;
+  }
+}
+
+// softmax over frames, weighted sum, projection + ReLU   (model.py:201-209)
+struct PoolParams {
+  const float* x;       // [B][C][W]
+  const float* scores;  // [B][W]
+  const float* projT;   // [C][E]
+  const float* proj_b;  // [E]
+  float* emb;           // [B][E]
+  int C, W, E;
+};
+
+__global__ __launch_bounds__(256) void attn_pool_proj_kernel(const PoolParams p) {
+  extern __shared__ float sm[];
+  float* w = sm;            // [W]
+  float* pooled = sm + ((p.W + 3) & ~3);  // [C]
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int t = tid; t < p.W; t += 256) mx = fmaxf(mx, p.scores[(size_t)b * p.W + t]);
+  mx = mst::wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int t = tid; t < p.W; t += 256) {
+    const float e = expf(p.scores[(size_t)b * p.W + t] - mx);
+    w[t] = e;
+    sum += e;
+  }
+  sum = mst::wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  const float* xb = p.x + (size_t)b * p.C * p.W;
+  for (int c = wave; c < p.C; c += 4) {
+    float v = 0.f;
+    for (int t = lane; t < p.W; t += 64) v = fmaf(xb[(size_t)c * p.W + t], w[t] * inv, v);
+    v = mst::wave_sum(v);
+    if (lane == 0) pooled[c] = v;
+  }
+  __syncthreads();
+  for (int e = tid; e < p.E; e += 256) {
+    float a = p.proj_b[e];
+    for (int c = 0; c < p.C; ++c) a = fmaf(p.projT[(size_t)c * p.E + e], pooled[c], a);
+    p.emb[(size_t)b * p.E + e] = fmaxf(a, 0.f);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct mst_encoder {
+  mst_encoder_config cfg{};
+  int sub = 0, H1 = 0, FD = 0, C = 0;
+  float *w1frag = nullptr, *w2frag = nullptr;
+  float *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;
+  float *w0t = nullptr, *b0 = nullptr, *w3t = nullptr, *b3 = nullptr, *hwt = nullptr, *hb = nullptr;
+  float *att0frag = nullptr, *att0_b = nullptr, *att2_w = nullptr, *projT = nullptr, *proj_b = nullptr;
+  float att2_b = 0.f;
+  int num_cus = 256;
+};
+
+namespace {
+
+struct WsLayout {
+  size_t film, aff1, aff2, pool1, pool_in, scores, total;
+  int W1, W2;
+};
+
+WsLayout ws_layout(const mst_encoder* e, int B, int frames) {
+  WsLayout L{};
+  const int ns = e->cfg.n_subbands;
+  L.W1 = frames / 5;
+  L.W2 = L.W1 / 4;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += mst::align_up(bytes, 256);
+    return at;
+  };
+  L.film = take((size_t)B * ns * 192 * 4);
+  L.aff1 = take((size_t)B * ns * 32 * 8);
+  L.aff2 = take((size_t)B * ns * 64 * 8);
+  L.pool1 = take((size_t)B * ns * 32 * e->H1 * L.W1 * 4);
+  L.pool_in = take((size_t)B * e->C * L.W2 * 4);
+  L.scores = take((size_t)B * L.W2 * 4);
+  L.total = o;
+  return L;
+}
+
+std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][cols] -> [cols][rows]
+  std::vector<float> t((size_t)rows * cols);
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = w[(size_t)r * cols + c];
+  return t;
+}
+
+// conv weights [nsub][COUT][CIN][7][7] -> [nsub][CIN/4][WCHP] with chunk layout [tap][nt][lane]
+std::vector<float> conv_fragments(const float* w, int nsub, int cout, int cin) {
+  const int nt = cout / 16, nch = cin / 4;
+  const int wch = 49 * nt * 64, wchp = (wch + 255) / 256 * 256;
+  std::vector<float> f((size_t)nsub * nch * wchp, 0.f);
+  for (int b = 0; b < nsub; ++b)
+    for (int ch = 0; ch < nch; ++ch)
+      for (int tap = 0; tap < 49; ++tap)
+        for (int n = 0; n < nt; ++n)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = n * 16 + (lane & 15), ci = 4 * ch + (lane >> 4);
+            f[((size_t)b * nch + ch) * wchp + ((size_t)tap * nt + n) * 64 + lane] =
+                w[(((size_t)b * cout + co) * cin + ci) * 49 + tap];
+          }
+  return f;
+}
+
+template <int LAYER, int SUB>
+hipError_t launch_conv(const ConvParams& cp, int grid, hipStream_t st) {
+  using C = CC<LAYER, SUB>;
+  constexpr int WCHP = (49 * C::NT * 64 + 255) / 256 * 256;
+  constexpr int PATCH = (4 * C::PR * C::PC + 3) / 4 * 4;
+  const size_t lds = (size_t)(2 * WCHP + kConvWaves * PATCH) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<LAYER, SUB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((conv_kernel<LAYER, SUB>), dim3(grid), dim3(kConvThreads), lds, st, cp);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const mst_encoder_weights* w) {
+  MST_REQUIRE(out, "mst_encoder_create: NULL out");
+  *out = nullptr;
+  MST_REQUIRE(cfg && w, "mst_encoder_create: NULL config/weights");
+  const int ns = cfg->n_subbands;
+  MST_REQUIRE(ns >= 1 && cfg->split_size >= 4 && cfg->overlap >= 1 && cfg->n_mels >= cfg->split_size,
+              "mst_encoder_create: bad band split (n_mels=%d split=%d overlap=%d n_sub=%d)", cfg->n_mels,
+              cfg->split_size, cfg->overlap, ns);
+  MST_REQUIRE((ns - 1) * cfg->overlap + cfg->split_size <= cfg->n_mels, "mst_encoder_create: sub-bands exceed n_mels");
+  const int sub = cfg->split_size / 10 > 1 ? cfg->split_size / 10 : 1;
+  MST_REQUIRE(sub == 1 || sub == 2, "mst_encoder_create: pool height split_size//10 = %d unsupported (1 or 2)", sub);
+  MST_REQUIRE(cfg->attn_hidden == 256, "mst_encoder_create: attn_hidden must be 256 (got %d)", cfg->attn_hidden);
+  MST_REQUIRE(cfg->feature_dim >= 1 && cfg->film_hidden >= 1 && cfg->embed_dim >= 1, "mst_encoder_create: bad dims");
+  for (const float* const* q = &w->conv1_w; q <= &w->proj_b; ++q)
+    MST_REQUIRE(*q != nullptr, "mst_encoder_create: NULL weight pointer");
+  mst_encoder* e = new mst_encoder();
+  e->cfg = *cfg;
+  e->sub = sub;
+  e->H1 = cfg->split_size / sub;
+  e->FD = e->H1 / 4;
+  e->C = 64 * ns * e->FD;
+  MST_REQUIRE(e->FD >= 1 && e->C % 4 == 0, "mst_encoder_create: bad pooled geometry");
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    e->num_cus = prop.multiProcessorCount;
+  const int H = cfg->film_hidden, Fd = cfg->feature_dim, A = cfg->attn_hidden, E = cfg->embed_dim, C = e->C;
+  // BN(eval) folded with the conv bias, in double
+  auto fold = [&](const float* cb, const float* bw, const float* bb, const float* mean, const float* var, int n,
+                  std::vector<float>& s, std::vector<float>& t) {
+    s.resize(n), t.resize(n);
+    for (int i = 0; i < n; ++i) {
+      const double sc = (double)bw[i] / std::sqrt((double)var[i] + (double)cfg->bn_eps);
+      s[i] = (float)sc;
+      t[i] = (float)(sc * ((double)cb[i] - (double)mean[i]) + (double)bb[i]);
+    }
+  };
+  std::vector<float> s1, t1, s2, t2;
+  fold(w->conv1_b, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, ns * 32, s1, t1);
+  fold(w->conv2_b, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, ns * 64, s2, t2);
+  auto f1 = conv_fragments(w->conv1_w, ns, 32, 8);
+  auto f2 = conv_fragments(w->conv2_w, ns, 64, 32);
+  auto w0t = transpose(w->mlp0_w, H, Fd), w3t = transpose(w->mlp3_w, H, H), hwt = transpose(w->head_w, ns * 192, H);
+  auto projT = transpose(w->proj_w, E, C);
+  std::vector<float> af((size_t)(C / 4) * (A / 16) * 64);
+  for (int s = 0; s < C / 4; ++s)
+    for (int n = 0; n < A / 16; ++n)
+      for (int lane = 0; lane < 64; ++lane)
+        af[((size_t)s * (A / 16) + n) * 64 + lane] = w->att0_w[(size_t)(n * 16 + (lane & 15)) * C + 4 * s + (lane >> 4)];
+  e->att2_b = w->att2_b[0];
+  int rc = 0;
+#define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
+#define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
+  UP(w1frag, f1); UP(w2frag, f2); UP(s1, s1); UP(t1, t1); UP(s2, s2); UP(t2, t2);
+  UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projT, projT); UP(att0frag, af);
+  UPP(b0, w->mlp0_b, H); UPP(b3, w->mlp3_b, H); UPP(hb, w->head_b, ns * 192);
+  UPP(att0_b, w->att0_b, A); UPP(att2_w, w->att2_w, A); UPP(proj_b, w->proj_b, E);
+#undef UP
+#undef UPP
+  if (rc) {
+    mst_encoder_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return MST_OK;
+}
+
+void mst_encoder_destroy(mst_encoder* e) {
+  if (!e) return;
+  float* ptrs[] = {e->w1frag, e->w2frag, e->s1, e->t1, e->s2, e->t2, e->w0t, e->b0, e->w3t, e->b3, e->hwt,
+                   e->hb, e->att0frag, e->att0_b, e->att2_w, e->projT, e->proj_b};
+  for (float* q : ptrs) (void)hipFree(q);
+  delete e;
+}
+
+size_t mst_encoder_workspace_bytes(const mst_encoder* e, int B, int frames) {
+  if (!e || B <= 0 || frames < 20) return 0;
+  return ws_layout(e, B, frames).total;
+}
+
+int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
+                        const mst_encoder_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && logmel && feats && emb, "mst_encoder_forward: NULL argument");
+  MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
+  const WsLayout L = ws_layout(e, B, frames);
+  MST_REQUIRE(L.W2 >= 1, "mst_encoder_forward: clip too short for two pooling stages (frames=%d)", frames);
+  if (!workspace || workspace_bytes < L.total)
+    return mst::fail(MST_ENOMEM, "mst_encoder_forward: workspace %zu B < required %zu B", workspace_bytes, L.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int ns = e->cfg.n_subbands;
+  float* film = (taps && taps->film) ? taps->film : reinterpret_cast<float*>(ws + L.film);
+  float* pool1 = (taps && taps->pool1) ? taps->pool1 : reinterpret_cast<float*>(ws + L.pool1);
+  float* pool_in = (taps && taps->pool_in) ? taps->pool_in : reinterpret_cast<float*>(ws + L.pool_in);
+  float2* aff1 = reinterpret_cast<float2*>(ws + L.aff1);
+  float2* aff2 = reinterpret_cast<float2*>(ws + L.aff2);
+  float* scores = reinterpret_cast<float*>(ws + L.scores);
+  auto mark = [&](int i) {
+    if (taps && taps->events[i]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(taps->events[i]), st);
+  };
+  mark(0);
+  {
+    FilmParams fp{feats, e->w0t, e->b0, e->w3t, e->b3, e->hwt, e->hb, e->s1, e->t1, e->s2, e->t2,
+                  film, aff1, aff2, e->cfg.feature_dim, e->cfg.film_hidden, ns};
+    const size_t lds = (size_t)(e->cfg.feature_dim + 2 * e->cfg.film_hidden) * sizeof(float);
+    hipLaunchKernelGGL(film_kernel, dim3(B), dim3(256), lds, st, fp);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  mark(1);
+  const int grid = e->num_cus;
+  {
+    ConvParams cp{};
+    cp.in = logmel, cp.wfrag = e->w1frag, cp.aff = aff1, cp.out = pool1, cp.B = B, cp.nsub = ns;
+    cp.in_rows = e->cfg.split_size, cp.in_cols = frames;
+    cp.in_cstride = e->cfg.n_mels * frames;
+    cp.in_bandoff = e->cfg.overlap * frames;
+    cp.in_clipstride = (long long)8 * e->cfg.n_mels * frames;
+    cp.out_rows = e->H1, cp.out_cols = L.W1;
+    cp.tiles_r = e->H1;
+    cp.tiles_c = e->sub == 2 ? (L.W1 + 7) / 8 : (L.W1 + 15) / 16;
+    cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+    const int g = std::min(grid, ns * cp.sets_per_band);
+    hipError_t err = e->sub == 2 ? launch_conv<1, 2>(cp, g, st) : launch_conv<1, 1>(cp, g, st);
+    if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 launch failed: %s", hipGetErrorString(err));
+  }
+  mark(2);
+  {
+    ConvParams cp{};
+    cp.in = pool1, cp.wfrag = e->w2frag, cp.aff = aff2, cp.out = pool_in, cp.B = B, cp.nsub = ns;
+    cp.in_rows = e->H1, cp.in_cols = L.W1;
+    cp.in_cstride = e->H1 * L.W1;
+    cp.in_bandoff = 32 * e->H1 * L.W1;
+    cp.in_clipstride = (long long)ns * 32 * e->H1 * L.W1;
+    cp.out_rows = e->FD, cp.out_cols = L.W2;
+    cp.tiles_r = (e->FD + 1) / 2;
+    cp.tiles_c = (L.W2 + 1) / 2;
+    cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+    const int g = std::min(grid, ns * cp.sets_per_band);
+    hipError_t err = launch_conv<2, 2>(cp, g, st);
+    if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 launch failed: %s", hipGetErrorString(err));
+  }
+  mark(3);
+  {
+    AttnParams ap{pool_in, e->att0frag, e->att0_b, e->att2_w, e->att2_b, scores, B, e->C, L.W2, e->cfg.attn_hidden};
+    const int mtiles = (B * L.W2 + 15) / 16;
+    hipLaunchKernelGGL((attn_scores_kernel<16>), dim3((mtiles + 3) / 4), dim3(256), 0, st, ap);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  mark(4);
+  {
+    PoolParams pp{pool_in, scores, e->projT, e->proj_b, emb, e->C, L.W2, e->cfg.embed_dim};
+    const size_t lds = (size_t)(((L.W2 + 3) & ~3) + e->C) * sizeof(float);
+    hipLaunchKernelGGL(attn_pool_proj_kernel, dim3(B), dim3(256), lds, st, pp);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  mark(5);
+  return MST_OK;
+}
+
+}  // extern "C"

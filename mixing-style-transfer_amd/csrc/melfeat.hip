@@ -804,7 +804,8 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
 
 void mst_plan_destroy(mst_plan* p) {
   if (!p) return;
-  hipFree(p->d_window), hipFree(p->d_tw), hipFree(p->d_post), hipFree(p->d_melw), hipFree(p->d_lanebands);
+  (void)hipFree(p->d_window), (void)hipFree(p->d_tw), (void)hipFree(p->d_post), (void)hipFree(p->d_melw),
+      (void)hipFree(p->d_lanebands);
   delete p;
 }
 

@@ -209,7 +209,8 @@ class HipEncoder:
             except Exception:
                 pass
 
-    def forward(self, logmel, feats, taps=False):
+    def forward(self, logmel, feats, taps=False, events=None):
+        """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
         B, _, M, Fr = logmel.shape
         L = _lib.lib()
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
@@ -224,6 +225,11 @@ class HipEncoder:
                        pool1=torch.empty(B, self.n_sub, 32, H1, W1, device=logmel.device),
                        pool_in=torch.empty(B, 64 * self.n_sub * self.freq_dim, W1 // 4, device=logmel.device))
             t = C.byref(_lib.EncoderTaps(out["film"].data_ptr(), out["pool1"].data_ptr(), out["pool_in"].data_ptr()))
+        elif events is not None:
+            tp = _lib.EncoderTaps()
+            for i, ev in enumerate(events):
+                tp.events[i] = ev.cuda_event
+            t = C.byref(tp)
         with torch.cuda.device(logmel.device):
             _lib.check(L.mst_encoder_forward(self._h, _lib.dptr(logmel), Fr, _lib.dptr(feats.contiguous().float()), B,
                                              _lib.dptr(emb), t, _lib.dptr(self._ws), need,
@@ -270,3 +276,23 @@ class MixingStyleEncoder(nn.Module):
         with torch.no_grad():
             logmel = self.audio_encoder.mel_preprocessor(stems_dict)
         return self.forward_from_logmel(logmel, mixing_features)
+
+
+def _smoke():
+    """One tiny end-to-end forward on cuda:0 checked against the CPU oracle (called by __graft_entry__.smoke)."""
+    from oracle import encoder as oenc
+    from oracle import features as ofeat
+    from .synth import synth_batch
+    torch.manual_seed(0)
+    m = MixingStyleEncoder(feature_dim=64).cuda().eval()
+    x = synth_batch(2, 33075)
+    stems = {s: x[:, 2 * i:2 * i + 2].cuda() for i, s in enumerate(STEMS)}
+    from .mixing_utils import MixingFeatureExtractor
+    feats = MixingFeatureExtractor().extract_all_features(stems)
+    with torch.no_grad():
+        emb = m(stems, feats).cpu()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oenc.encoder_forward(sd, x, ofeat.extract_all_features(x))
+    err = (emb - ref).abs().max().item() / ref.abs().max().item()
+    print(f"smoke: embedding err {err:.2e} (rel to max)")
+    assert err < 2e-4
