@@ -118,17 +118,19 @@ def main():
         return e
 
     marks = []
+    pool = [[ev() for _ in range(9)] for _ in range(a.steps)]   # events are created outside the timed region
 
     def step(timed):
         with torch.no_grad():
-            e0, e1, e2 = (ev(), ev(), ev()) if timed else (None, None, None)
+            evs = pool[len(marks)] if timed else None
+            e0, e1, e2 = evs[:3] if timed else (None, None, None)
             if timed:
                 e0.record()
             feats, logmel = fe.features_and_logmel(stems)
             if timed:
                 e1.record()
             if backend == "hip":
-                kev = [ev() for _ in range(6)] if timed else None
+                kev = evs[3:] if timed else None
                 emb = model.hip_encoder().forward(logmel, feats, events=kev)
             else:
                 kev = None

@@ -69,6 +69,12 @@ size_t mst_melfeat_workspace_bytes(const mst_plan* plan, int B, int T);
  * Requires T > n_fft/2 (reflect padding), same as torch.stft.                               */
 int mst_melfeat_forward(const mst_plan* plan, const float* stems, int B, int T, float* logmel,
                         float* feats, void* workspace, size_t workspace_bytes, void* stream);
+/* Same, for the four separate tensors that baseline_collate_fn (src/data.py:291-328) returns:
+ * stems4[s] = dev [B][2][T] for s = vocals, bass, drums, other; clip_stride = floats between consecutive
+ * clips of one stem (2*T for contiguous (B,2,T) tensors, 8*T for views of a packed [B][8][T] tensor). */
+int mst_melfeat_forward_stems(const mst_plan* plan, const float* const stems4[4], long long clip_stride,
+                              int B, int T, float* logmel, float* feats, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage B: FiLM MLP + band-split Conv2D/BN/FiLM/ReLU/MaxPool x2 + attention pooling (eval).

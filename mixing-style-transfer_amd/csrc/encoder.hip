@@ -40,41 +40,70 @@ struct FilmParams {
 };
 
 __global__ __launch_bounds__(256) void film_kernel(const FilmParams p) {
+  // grid = (clip, group of sub-bands); the two small hidden layers are recomputed per group (82 k MACs)
   extern __shared__ float sm[];
   float* f = sm;            // [Fd]
   float* h1 = f + p.Fd;     // [H]
   float* h2 = h1 + p.H;     // [H]
+  float* fl = h2 + p.H;     // [bands_per_group * 192] film outputs of this group
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int bpg = (p.nsub + gridDim.y - 1) / gridDim.y;
+  const int band0 = blockIdx.y * bpg, band1 = min(p.nsub, band0 + bpg);
+  if (band0 >= band1) return;
   for (int i = tid; i < p.Fd; i += 256) f[i] = p.feats[(size_t)b * p.Fd + i];
   __syncthreads();
   for (int j = tid; j < p.H; j += 256) {
-    float a = p.b0[j];
-    for (int i = 0; i < p.Fd; ++i) a = fmaf(p.w0t[(size_t)i * p.H + j], f[i], a);
-    h1[j] = fmaxf(a, 0.f);
+    float a0 = p.b0[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 3 < p.Fd; i += 4) {
+      a0 = fmaf(p.w0t[(size_t)i * p.H + j], f[i], a0);
+      a1 = fmaf(p.w0t[(size_t)(i + 1) * p.H + j], f[i + 1], a1);
+      a2 = fmaf(p.w0t[(size_t)(i + 2) * p.H + j], f[i + 2], a2);
+      a3 = fmaf(p.w0t[(size_t)(i + 3) * p.H + j], f[i + 3], a3);
+    }
+    for (; i < p.Fd; ++i) a0 = fmaf(p.w0t[(size_t)i * p.H + j], f[i], a0);
+    h1[j] = fmaxf((a0 + a1) + (a2 + a3), 0.f);
   }
   __syncthreads();
   for (int j = tid; j < p.H; j += 256) {
-    float a = p.b3[j];
-    for (int i = 0; i < p.H; ++i) a = fmaf(p.w3t[(size_t)i * p.H + j], h1[i], a);
-    h2[j] = fmaxf(a, 0.f);
+    float a0 = p.b3[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 3 < p.H; i += 4) {
+      a0 = fmaf(p.w3t[(size_t)i * p.H + j], h1[i], a0);
+      a1 = fmaf(p.w3t[(size_t)(i + 1) * p.H + j], h1[i + 1], a1);
+      a2 = fmaf(p.w3t[(size_t)(i + 2) * p.H + j], h1[i + 2], a2);
+      a3 = fmaf(p.w3t[(size_t)(i + 3) * p.H + j], h1[i + 3], a3);
+    }
+    for (; i < p.H; ++i) a0 = fmaf(p.w3t[(size_t)i * p.H + j], h1[i], a0);
+    h2[j] = fmaxf((a0 + a1) + (a2 + a3), 0.f);
   }
   __syncthreads();
   const int nout = p.nsub * 192;
   float* film = p.film + (size_t)b * nout;
-  for (int o = tid; o < nout; o += 256) {
-    float a = p.hb[o];
-    for (int i = 0; i < p.H; ++i) a = fmaf(p.hwt[(size_t)i * nout + o], h2[i], a);
-    film[o] = a;
+  for (int o = band0 * 192 + tid; o < band1 * 192; o += 256) {
+    float a0 = p.hb[o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    for (; i + 3 < p.H; i += 4) {
+      a0 = fmaf(p.hwt[(size_t)i * nout + o], h2[i], a0);
+      a1 = fmaf(p.hwt[(size_t)(i + 1) * nout + o], h2[i + 1], a1);
+      a2 = fmaf(p.hwt[(size_t)(i + 2) * nout + o], h2[i + 2], a2);
+      a3 = fmaf(p.hwt[(size_t)(i + 3) * nout + o], h2[i + 3], a3);
+    }
+    for (; i < p.H; ++i) a0 = fmaf(p.hwt[(size_t)i * nout + o], h2[i], a0);
+    const float v = (a0 + a1) + (a2 + a3);
+    film[o] = v;
+    fl[o - band0 * 192] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < p.nsub * 96; idx += 256) {
+  for (int idx = band0 * 96 + tid; idx < band1 * 96; idx += 256) {
     const int band = idx / 96, c = idx % 96;
+    const float* fb = fl + (band - band0) * 192;
     if (c < 32) {
-      const float g = film[band * 192 + c], be = film[band * 192 + 32 + c];
+      const float g = fb[c], be = fb[32 + c];
       p.aff1[((size_t)b * p.nsub + band) * 32 + c] = make_float2(g * p.s1[band * 32 + c], fmaf(g, p.t1[band * 32 + c], be));
     } else {
       const int c2 = c - 32;
-      const float g = film[band * 192 + 64 + c2], be = film[band * 192 + 128 + c2];
+      const float g = fb[64 + c2], be = fb[128 + c2];
       p.aff2[((size_t)b * p.nsub + band) * 64 + c2] =
           make_float2(g * p.s2[band * 64 + c2], fmaf(g, p.t2[band * 64 + c2], be));
     }
@@ -286,71 +315,82 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 
 // ------------------------------------------------------------------------------------------
 // Attention scores: s[b][t] = w2 . tanh(W1 x[b,:,t] + b1) + b2      (model.py:198-200)
-// fp32-MFMA GEMM, one wave = 16 frames x all hidden units; W1 pre-swizzled into B-fragment order.
+// fp32-MFMA GEMM.  One workgroup = 16 frames; its 4 waves split the 256 hidden units (4 N-tiles each) and
+// combine their partial dot products through LDS.  W1 is pre-swizzled into B-fragment order.
 // ------------------------------------------------------------------------------------------
 struct AttnParams {
   const float* x;       // pool_in [B][C][W]
-  const float* w1frag;  // [C/4][NTA][64]
+  const float* w1frag;  // [C/4][16][64]
   const float *b1, *w2;
   float b2;
   float* scores;        // [B][W]
   int B, C, W, A;
 };
 
-template <int NTA>
 __global__ __launch_bounds__(256) void attn_scores_kernel(const AttnParams p) {
+  __shared__ float part_s[4][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mt = blockIdx.x * 4 + wave;
+  const int mt = blockIdx.x;
   const int M = p.B * p.W;
-  if (mt * 16 >= M) return;
   const int kq = lane >> 4, i = lane & 15;
   const int m = mt * 16 + i;
   const bool ok = m < M;
   const int b = ok ? m / p.W : 0, t = ok ? m % p.W : 0;
   const float* xa = p.x + ((size_t)b * p.C + kq) * p.W + t;
-  f32x4 acc[NTA];
+  f32x4 acc[4];
 #pragma unroll
-  for (int n = 0; n < NTA; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int steps = p.C / 4;
-  const float* wf = p.w1frag + lane;
-  for (int s = 0; s < steps; ++s) {
-    const float a = ok ? xa[(size_t)s * 4 * p.W] : 0.f;
+  const float* wf = p.w1frag + (size_t)(wave * 4) * 64 + lane;
+  float a_nx = ok ? xa[0] : 0.f;
+  float b_nx[4];
 #pragma unroll
-    for (int n = 0; n < NTA; ++n) {
-      const float bb = wf[((size_t)s * NTA + n) * 64];
-      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc[n], 0, 0, 0);
+  for (int n = 0; n < 4; ++n) b_nx[n] = wf[n * 64];
+  for (int s = 0; s < steps; ++s) {
+    const float a = a_nx;
+    float bb[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bb[n] = b_nx[n];
+    if (s + 1 < steps) {  // software prefetch of the next k-step
+      a_nx = ok ? xa[(size_t)(s + 1) * 4 * p.W] : 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b_nx[n] = wf[((size_t)(s + 1) * 16 + n) * 64];
     }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[n], acc[n], 0, 0, 0);
   }
-  // rows 4*kq + r of this M-tile live in lane group kq; columns n*16 + i
+  // rows 4*kq + r of this M-tile live in lane group kq; columns (wave*4 + n)*16 + i
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float part = 0.f;
 #pragma unroll
-    for (int n = 0; n < NTA; ++n) {
-      const int h = n * 16 + i;
+    for (int n = 0; n < 4; ++n) {
+      const int h = (wave * 4 + n) * 16 + i;
       part = fmaf(p.w2[h], tanhf(acc[n][r] + p.b1[h]), part);
     }
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    const int mr = mt * 16 + 4 * kq + r;
-    if (i == 0 && mr < M) p.scores[mr] = part + p.b2;
+    if (i == 0) part_s[wave][4 * kq + r] = part;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int mr = mt * 16 + threadIdx.x;
+    if (mr < M)
+      p.scores[mr] = ((part_s[0][threadIdx.x] + part_s[1][threadIdx.x]) + (part_s[2][threadIdx.x] + part_s[3][threadIdx.x])) + p.b2;
   }
 }
 
-// softmax over frames, weighted sum, projection + ReLU   (model.py:201-209)
+// softmax over frames + weighted sum: pooled[b][c] = sum_t softmax(s[b])[t] * x[b][c][t]   (model.py:201-206)
 struct PoolParams {
   const float* x;       // [B][C][W]
   const float* scores;  // [B][W]
-  const float* projT;   // [C][E]
-  const float* proj_b;  // [E]
-  float* emb;           // [B][E]
-  int C, W, E;
+  float* pooled;        // [B][C]
+  int C, W;
 };
 
-__global__ __launch_bounds__(256) void attn_pool_proj_kernel(const PoolParams p) {
+__global__ __launch_bounds__(256) void attn_pool_kernel(const PoolParams p) {
   extern __shared__ float sm[];
-  float* w = sm;            // [W]
-  float* pooled = sm + ((p.W + 3) & ~3);  // [C]
+  float* w = sm;  // [W] normalised weights
   __shared__ float red[8];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float mx = -INFINITY;
@@ -368,20 +408,68 @@ __global__ __launch_bounds__(256) void attn_pool_proj_kernel(const PoolParams p)
   sum = mst::wave_sum(sum);
   if (lane == 0) red[4 + wave] = sum;
   __syncthreads();
-  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+  // this block's slice of channels: 16 lanes per channel, 4 channels per wave pass
+  const int c_per_blk = (p.C + gridDim.y - 1) / gridDim.y;
+  const int c0 = blockIdx.y * c_per_blk, c1 = min(p.C, c0 + c_per_blk);
   const float* xb = p.x + (size_t)b * p.C * p.W;
-  for (int c = wave; c < p.C; c += 4) {
+  const int sub = lane >> 4, l16 = lane & 15;
+  for (int c = c0 + wave * 4 + sub; c < c1 + 3; c += 16) {
     float v = 0.f;
-    for (int t = lane; t < p.W; t += 64) v = fmaf(xb[(size_t)c * p.W + t], w[t] * inv, v);
-    v = mst::wave_sum(v);
-    if (lane == 0) pooled[c] = v;
+    if (c < c1)
+      for (int t = l16; t < p.W; t += 16) v = fmaf(xb[(size_t)c * p.W + t], w[t] * inv, v);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (l16 == 0 && c < c1) p.pooled[(size_t)b * p.C + c] = v;
   }
-  __syncthreads();
-  for (int e = tid; e < p.E; e += 256) {
-    float a = p.proj_b[e];
-    for (int c = 0; c < p.C; ++c) a = fmaf(p.projT[(size_t)c * p.E + e], pooled[c], a);
-    p.emb[(size_t)b * p.E + e] = fmaxf(a, 0.f);
+}
+
+// projection + ReLU: emb[b][e] = relu(bp[e] + sum_c Wp[e][c] pooled[b][c])   (model.py:208-209)
+// fp32-MFMA GEMM, one wave = one 16-column tile of E x up to 8 row tiles of clips; Wp in B-fragment order.
+struct ProjParams {
+  const float* pooled;  // [B][C]
+  const float* wfrag;   // [C/4][E/16][64]
+  const float* bias;    // [E]
+  float* emb;           // [B][E]
+  int B, C, E;
+};
+
+__global__ __launch_bounds__(256) void proj_kernel(const ProjParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nt = blockIdx.x * 4 + wave, NTE = p.E / 16;
+  if (nt >= NTE) return;
+  const int kq = lane >> 4, i = lane & 15;
+  const int m0 = blockIdx.y * 128;
+  f32x4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* ap[8];
+  bool okr[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int m = m0 + t * 16 + i;
+    okr[t] = m < p.B;
+    ap[t] = p.pooled + (size_t)(okr[t] ? m : 0) * p.C + kq;
   }
+  const float* wf = p.wfrag + (size_t)nt * 64 + lane;
+  const int steps = p.C / 4;
+  for (int s = 0; s < steps; ++s) {
+    const float bb = wf[(size_t)s * NTE * 64];
+    float a[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) a[t] = okr[t] ? ap[t][4 * s] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bb, acc[t], 0, 0, 0);
+  }
+  const int e = nt * 16 + i;
+  const float be = p.bias[e];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + t * 16 + 4 * kq + r;
+      if (m < p.B) p.emb[(size_t)m * p.E + e] = fmaxf(acc[t][r] + be, 0.f);
+    }
 }
 
 }  // namespace
@@ -395,7 +483,7 @@ struct mst_encoder {
   float *w1frag = nullptr, *w2frag = nullptr;
   float *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;
   float *w0t = nullptr, *b0 = nullptr, *w3t = nullptr, *b3 = nullptr, *hwt = nullptr, *hb = nullptr;
-  float *att0frag = nullptr, *att0_b = nullptr, *att2_w = nullptr, *projT = nullptr, *proj_b = nullptr;
+  float *att0frag = nullptr, *att0_b = nullptr, *att2_w = nullptr, *projfrag = nullptr, *proj_b = nullptr;
   float att2_b = 0.f;
   int num_cus = 256;
 };
@@ -403,7 +491,7 @@ struct mst_encoder {
 namespace {
 
 struct WsLayout {
-  size_t film, aff1, aff2, pool1, pool_in, scores, total;
+  size_t film, aff1, aff2, pool1, pool_in, scores, pooled, total;
   int W1, W2;
 };
 
@@ -424,6 +512,7 @@ WsLayout ws_layout(const mst_encoder* e, int B, int frames) {
   L.pool1 = take((size_t)B * ns * 32 * e->H1 * L.W1 * 4);
   L.pool_in = take((size_t)B * e->C * L.W2 * 4);
   L.scores = take((size_t)B * L.W2 * 4);
+  L.pooled = take((size_t)B * e->C * 4);
   L.total = o;
   return L;
 }
@@ -458,9 +547,13 @@ hipError_t launch_conv(const ConvParams& cp, int grid, hipStream_t st) {
   constexpr int WCHP = (49 * C::NT * 64 + 255) / 256 * 256;
   constexpr int PATCH = (4 * C::PR * C::PC + 3) / 4 * 4;
   const size_t lds = (size_t)(2 * WCHP + kConvWaves * PATCH) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<LAYER, SUB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static bool attr_set = false;  // one driver call per kernel per process, not per launch
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<LAYER, SUB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
   hipLaunchKernelGGL((conv_kernel<LAYER, SUB>), dim3(grid), dim3(kConvThreads), lds, st, cp);
   return hipGetLastError();
 }
@@ -512,7 +605,12 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   auto f1 = conv_fragments(w->conv1_w, ns, 32, 8);
   auto f2 = conv_fragments(w->conv2_w, ns, 64, 32);
   auto w0t = transpose(w->mlp0_w, H, Fd), w3t = transpose(w->mlp3_w, H, H), hwt = transpose(w->head_w, ns * 192, H);
-  auto projT = transpose(w->proj_w, E, C);
+  MST_REQUIRE(E % 16 == 0, "mst_encoder_create: embed_dim must be a multiple of 16 (got %d)", E);
+  std::vector<float> pfrag((size_t)(C / 4) * (E / 16) * 64);
+  for (int s = 0; s < C / 4; ++s)
+    for (int n = 0; n < E / 16; ++n)
+      for (int lane = 0; lane < 64; ++lane)
+        pfrag[((size_t)s * (E / 16) + n) * 64 + lane] = w->proj_w[(size_t)(n * 16 + (lane & 15)) * C + 4 * s + (lane >> 4)];
   std::vector<float> af((size_t)(C / 4) * (A / 16) * 64);
   for (int s = 0; s < C / 4; ++s)
     for (int n = 0; n < A / 16; ++n)
@@ -523,7 +621,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
 #define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
 #define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
   UP(w1frag, f1); UP(w2frag, f2); UP(s1, s1); UP(t1, t1); UP(s2, s2); UP(t2, t2);
-  UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projT, projT); UP(att0frag, af);
+  UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projfrag, pfrag); UP(att0frag, af);
   UPP(b0, w->mlp0_b, H); UPP(b3, w->mlp3_b, H); UPP(hb, w->head_b, ns * 192);
   UPP(att0_b, w->att0_b, A); UPP(att2_w, w->att2_w, A); UPP(proj_b, w->proj_b, E);
 #undef UP
@@ -539,7 +637,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
 void mst_encoder_destroy(mst_encoder* e) {
   if (!e) return;
   float* ptrs[] = {e->w1frag, e->w2frag, e->s1, e->t1, e->s2, e->t2, e->w0t, e->b0, e->w3t, e->b3, e->hwt,
-                   e->hb, e->att0frag, e->att0_b, e->att2_w, e->projT, e->proj_b};
+                   e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b};
   for (float* q : ptrs) (void)hipFree(q);
   delete e;
 }
@@ -573,8 +671,10 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
   {
     FilmParams fp{feats, e->w0t, e->b0, e->w3t, e->b3, e->hwt, e->hb, e->s1, e->t1, e->s2, e->t2,
                   film, aff1, aff2, e->cfg.feature_dim, e->cfg.film_hidden, ns};
-    const size_t lds = (size_t)(e->cfg.feature_dim + 2 * e->cfg.film_hidden) * sizeof(float);
-    hipLaunchKernelGGL(film_kernel, dim3(B), dim3(256), lds, st, fp);
+    const int groups = ns < 4 ? ns : 4;
+    const int bpg = (ns + groups - 1) / groups;
+    const size_t lds = (size_t)(e->cfg.feature_dim + 2 * e->cfg.film_hidden + bpg * 192) * sizeof(float);
+    hipLaunchKernelGGL(film_kernel, dim3(B, groups), dim3(256), lds, st, fp);
     MST_HIP_CHECK(hipGetLastError());
   }
   mark(1);
@@ -614,14 +714,18 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
   {
     AttnParams ap{pool_in, e->att0frag, e->att0_b, e->att2_w, e->att2_b, scores, B, e->C, L.W2, e->cfg.attn_hidden};
     const int mtiles = (B * L.W2 + 15) / 16;
-    hipLaunchKernelGGL((attn_scores_kernel<16>), dim3((mtiles + 3) / 4), dim3(256), 0, st, ap);
+    hipLaunchKernelGGL(attn_scores_kernel, dim3(mtiles), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
   mark(4);
   {
-    PoolParams pp{pool_in, scores, e->projT, e->proj_b, emb, e->C, L.W2, e->cfg.embed_dim};
-    const size_t lds = (size_t)(((L.W2 + 3) & ~3) + e->C) * sizeof(float);
-    hipLaunchKernelGGL(attn_pool_proj_kernel, dim3(B), dim3(256), lds, st, pp);
+    float* pooled = reinterpret_cast<float*>(ws + L.pooled);
+    PoolParams pp{pool_in, scores, pooled, e->C, L.W2};
+    const int slices = (e->C + 127) / 128;
+    hipLaunchKernelGGL(attn_pool_kernel, dim3(B, slices), dim3(256), (size_t)((L.W2 + 3) & ~3) * sizeof(float), st, pp);
+    MST_HIP_CHECK(hipGetLastError());
+    ProjParams pj{pooled, e->projfrag, e->proj_b, emb, B, e->C, e->cfg.embed_dim};
+    hipLaunchKernelGGL(proj_kernel, dim3((e->cfg.embed_dim / 16 + 3) / 4, (B + 127) / 128), dim3(256), 0, st, pj);
     MST_HIP_CHECK(hipGetLastError());
   }
   mark(5);

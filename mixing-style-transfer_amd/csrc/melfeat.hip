@@ -51,7 +51,8 @@ struct LaneBand {  // one mel band owned by a lane
 };
 
 struct KParams {
-  const float* stems;
+  const float* stem[4];      // per-stem base pointers, each [B][2][T] with clip stride `clip_stride` floats
+  long long clip_stride;     // 8*T for a packed [B][8][T] tensor, 2*T for four separate [B][2][T] tensors
   float* logmel;
   float* partials;
   const float* window;
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll
   for (int r = 0; r < NB; ++r) lb[r] = p.lanebands[r * 64 + lane];
 
-  const float* xclip = p.stems + (size_t)clip * 8 * p.T;
+  auto chan = [&](int c) { return p.stem[c >> 1] + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T; };
   float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
   float* red = reinterpret_cast<float*>(s_scr);  // workgroup reduction buffer (aliases FFT scratch)
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     float piv[8], sq[8], pk[8], ds[8], dq[8], cr[4], mid[4], side[4], mix = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      piv[c] = n_own > 0 ? xclip[(size_t)c * p.T + o_begin] : 0.f;
+      piv[c] = n_own > 0 ? chan(c)[o_begin] : 0.f;
       sq[c] = pk[c] = ds[c] = dq[c] = 0.f;
     }
 #pragma unroll
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
       const bool full = (i + 3 < n_own);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        const float* src = xclip + (size_t)c * p.T + o_begin + i;
+        const float* src = chan(c) + o_begin + i;
         if (full && p.vec4_ok) {
           const float4 q = *reinterpret_cast<const float4*>(src);
           x[c][0] = q.x, x[c][1] = q.y, x[c][2] = q.z, x[c][3] = q.w;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
           float mel[NB];
-          frame_mel<NFFT, NB>(p, xclip + (size_t)(2 * s + c) * p.T, frame, lane, s_win, s_tw, s_post, s_melw,
+          frame_mel<NFFT, NB>(p, chan(2 * s + c), frame, lane, s_win, s_tw, s_post, s_melw,
                               scr, lb, mel);
           float lsum = 0.f, msum = 0.f;
 #pragma unroll
@@ -673,9 +674,13 @@ __global__ __launch_bounds__(256) void melfeat_finalize_kernel(const FParams p) 
 
 template <int NFFT, int NB>
 hipError_t launch_melfeat(const KParams& kp, int grid, size_t lds, hipStream_t st) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_kernel<NFFT, NB>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static size_t attr_lds = 0;  // raise the dynamic-LDS limit once per kernel (and again only if it grows)
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_kernel<NFFT, NB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_lds = lds;
+  }
   hipLaunchKernelGGL((melfeat_kernel<NFFT, NB>), dim3(grid), dim3(kThreads), lds, st, kp);
   return hipGetLastError();
 }
@@ -821,6 +826,14 @@ size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
 int mst_melfeat_forward(const mst_plan* p, const float* stems, int B, int T, float* logmel, float* feats,
                         void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(p && stems, "mst_melfeat_forward: NULL plan/stems");
+  const float* four[4] = {stems, stems + 2 * (size_t)T, stems + 4 * (size_t)T, stems + 6 * (size_t)T};
+  return mst_melfeat_forward_stems(p, four, (long long)8 * T, B, T, logmel, feats, workspace, workspace_bytes, stream);
+}
+
+int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], long long clip_stride, int B, int T,
+                              float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(p && stems4 && stems4[0] && stems4[1] && stems4[2] && stems4[3], "mst_melfeat_forward: NULL plan/stems");
+  MST_REQUIRE(clip_stride >= 2LL * T, "mst_melfeat_forward_stems: clip_stride %lld < 2*T", clip_stride);
   MST_REQUIRE(B > 0 && T > p->n_fft / 2, "mst_melfeat_forward: need B>0 and T > n_fft/2 (reflect pad); B=%d T=%d", B, T);
   MST_REQUIRE((long long)B * 8 * T < (1LL << 40), "mst_melfeat_forward: input too large");
   const size_t need = mst_melfeat_workspace_bytes(p, B, T);
@@ -829,16 +842,19 @@ int mst_melfeat_forward(const mst_plan* p, const float* stems, int B, int T, flo
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int F = 1 + T / p->hop;
   KParams kp{};
-  kp.stems = stems, kp.logmel = logmel, kp.partials = reinterpret_cast<float*>(workspace);
+  for (int i = 0; i < 4; ++i) kp.stem[i] = stems4[i];
+  kp.clip_stride = clip_stride;
+  kp.logmel = logmel, kp.partials = reinterpret_cast<float*>(workspace);
   kp.window = p->d_window, kp.tw = p->d_tw, kp.post = p->d_post, kp.melw = p->d_melw, kp.lanebands = p->d_lanebands;
   kp.B = B, kp.T = T, kp.F = F, kp.M = p->n_mels, kp.hop = p->hop;
   kp.tw_count = p->tw_count, kp.nnz = p->nnz;
   kp.frames_per_run = p->batches_per_run * kTF;
   kp.runs_per_clip = runs_per_clip(p, F);
   kp.pstride = pstride_of(p);
-  const bool base16 = (reinterpret_cast<uintptr_t>(stems) & 15) == 0;
-  kp.vec_ok = base16 && (T % 2 == 0) && (p->hop % 2 == 0);
-  kp.vec4_ok = base16 && (T % 4 == 0) && (p->hop % 4 == 0);
+  bool base16 = true;
+  for (int i = 0; i < 4; ++i) base16 = base16 && (reinterpret_cast<uintptr_t>(stems4[i]) & 15) == 0;
+  kp.vec_ok = base16 && (T % 2 == 0) && (p->hop % 2 == 0) && (clip_stride % 2 == 0);
+  kp.vec4_ok = base16 && (T % 4 == 0) && (p->hop % 4 == 0) && (clip_stride % 4 == 0);
   const int nc = p->nc;
   size_t lds = (size_t)(nc + p->tw_count + nc + kWaves * (nc + nc / 8)) * sizeof(float2) +
                (size_t)(((p->nnz + 3) & ~3) + 2 * p->n_mels * kTileStride) * sizeof(float);

@@ -69,6 +69,32 @@ class MelFeatPlan:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws, need
 
+    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True):
+        """{stem: (B,2,T) | (2,T)} fp32 CUDA -> (logmel, feats) without concatenating the stems: the kernel reads the
+        four tensors in place (views of one packed (B,8,T) tensor work too, any common clip stride)."""
+        parts = [stems_dict[s] for s in STEMS]
+        if parts[0].dim() == 2:
+            parts = [q.unsqueeze(0) for q in parts]
+        if not parts[0].is_cuda:
+            raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
+        B, ch, T = parts[0].shape
+        ok = all(q.dtype == torch.float32 and tuple(q.shape) == (B, 2, T) and q.stride(2) == 1 and q.stride(1) == T
+                 and q.stride(0) == parts[0].stride(0) for q in parts) and (B == 1 or parts[0].stride(0) >= 2 * T)
+        if not ok:
+            return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats)
+        dev = parts[0].device
+        F = self.frames(T)
+        logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=dev) if want_logmel else None
+        feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=dev) if want_feats else None
+        ws, need = self._workspace(B, T, dev)
+        ptrs = (C.c_void_p * 4)(*[q.data_ptr() for q in parts])
+        stride = parts[0].stride(0) if B > 1 else 2 * T
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mst_melfeat_forward_stems(self._h, ptrs, stride, B, T, _lib.dptr(logmel),
+                                                            _lib.dptr(feats), _lib.dptr(ws), need, _lib.stream_ptr(dev)),
+                       "mst_melfeat_forward_stems")
+        return logmel, feats
+
     def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True):
         """stems8 (B, 8, T) fp32 CUDA contiguous -> (logmel (B,8,M,F) | None, feats (B,Fd) | None)."""
         if not stems8.is_cuda:
@@ -141,13 +167,13 @@ class MixingFeatureExtractor:
 
     def features_and_logmel(self, stems_dict):
         """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F))."""
-        lm, f = self.plan().forward(stems_to_tensor(stems_dict), True, True)
+        lm, f = self.plan().forward_stems(stems_dict, True, True)
         return f, lm
 
     def extract_all_features(self, stems_dict):
         """stems_dict {stem: (2,T)} -> (feature_dim,)  [reference]; {stem: (B,2,T)} -> (B, feature_dim)."""
         batched = next(iter(stems_dict.values())).dim() == 3
-        _, f = self.plan().forward(stems_to_tensor(stems_dict), False, True)
+        _, f = self.plan().forward_stems(stems_dict, False, True)
         return f if batched else f[0]
 
     # ---- per-group views of the fused feature vector (reference public sub-methods)

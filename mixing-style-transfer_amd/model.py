@@ -56,7 +56,7 @@ class MelSpectrogramPreprocessor(nn.Module):
         self._plan = None
 
     def forward(self, stems_dict):
-        lm, _ = self.plan().forward(stems_to_tensor(stems_dict), True, False)
+        lm, _ = self.plan().forward_stems(stems_dict, True, False)
         return lm
 
 
