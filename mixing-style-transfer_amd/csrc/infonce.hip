@@ -1,0 +1,93 @@
+// InfoNCE forward on (all-gathered) embeddings.  Replaces InfoNCELoss.forward src/loss.py:31-136:
+//   E = normalize(E); S = E E^T / tau; row-max subtraction; pos_i = sum_{j != i, lab_j == lab_i} exp(S_ij),
+//   neg_i = sum_{lab_j != lab_i} exp(S_ij); loss_i = -log(pos_i / (pos_i + neg_i + 1e-8)) for anchors with pos_i > 0.
+// One workgroup per local anchor row; no host sync per anchor (the reference syncs N times).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* emb, float* inv_norm, int D) {
+  __shared__ float red[4];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  float a = 0.f;
+  for (int d = tid; d < D; d += 256) {
+    const float v = emb[(size_t)r * D + d];
+    a = fmaf(v, v, a);
+  }
+  a = mst::wave_sum(a);
+  if ((tid & 63) == 0) red[tid >> 6] = a;
+  __syncthreads();
+  if (tid == 0) inv_norm[r] = 1.0f / fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);  // F.normalize eps
+}
+
+__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* emb, const int64_t* labels, const float* inv_norm,
+                                                           float* sim, int N, int D, int row0, float inv_tau, float* out) {
+  extern __shared__ float srow[];  // [D] normalised anchor
+  __shared__ float red[12];
+  const int i = row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float ni = inv_norm[i];
+  for (int d = tid; d < D; d += 256) srow[d] = emb[(size_t)i * D + d] * ni;
+  __syncthreads();
+  float* s = sim + (size_t)blockIdx.x * N;
+  float mx = -INFINITY;
+  for (int j = wave; j < N; j += 4) {  // one wave per column: coalesced dot product
+    const float* ej = emb + (size_t)j * D;
+    float a = 0.f;
+    for (int d = lane; d < D; d += 64) a = fmaf(srow[d], ej[d], a);
+    a = mst::wave_sum(a) * inv_norm[j] * inv_tau;
+    if (lane == 0) s[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int64_t li = labels[i];
+  float pos = 0.f, neg = 0.f;
+  for (int j = tid; j < N; j += 256) {
+    const float e = expf(s[j] - mx);
+    const bool same = labels[j] == li;
+    if (same && j != i) pos += e;
+    if (!same) neg += e;
+  }
+  pos = mst::wave_sum(pos), neg = mst::wave_sum(neg);
+  if (lane == 0) red[4 + wave] = pos, red[8 + wave] = neg;
+  __syncthreads();
+  if (tid == 0) {
+    pos = (red[4] + red[5]) + (red[6] + red[7]);
+    neg = (red[8] + red[9]) + (red[10] + red[11]);
+    if (pos > 0.f) {
+      atomicAdd(out, -logf(pos / (pos + neg + 1e-8f)));
+      atomicAdd(out + 1, 1.0f);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t mst_infonce_workspace_bytes(int N, int D) {
+  if (N <= 0 || D <= 0) return 0;
+  return mst::align_up((size_t)N * sizeof(float), 256) + mst::align_up((size_t)N * N * sizeof(float), 256);
+}
+
+int mst_infonce_forward(const float* emb, const int64_t* labels, int N, int D, int row0, int rows, float temperature,
+                        float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(emb && labels && out, "mst_infonce_forward: NULL argument");
+  MST_REQUIRE(N > 0 && D > 0 && row0 >= 0 && rows > 0 && row0 + rows <= N && temperature > 0.f,
+              "mst_infonce_forward: bad sizes N=%d D=%d row0=%d rows=%d", N, D, row0, rows);
+  const size_t need = mst_infonce_workspace_bytes(N, D);
+  if (!workspace || workspace_bytes < need)
+    return mst::fail(MST_ENOMEM, "mst_infonce_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  float* inv_norm = reinterpret_cast<float*>(workspace);
+  float* sim = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + mst::align_up((size_t)N * sizeof(float), 256));
+  MST_HIP_CHECK(hipMemsetAsync(out, 0, 2 * sizeof(float), st));
+  hipLaunchKernelGGL(l2norm_kernel, dim3(N), dim3(256), 0, st, emb, inv_norm, D);
+  hipLaunchKernelGGL(infonce_rows_kernel, dim3(rows), dim3(256), (size_t)D * sizeof(float), st, emb, labels, inv_norm, sim,
+                     N, D, row0, 1.0f / temperature, out);
+  MST_HIP_CHECK(hipGetLastError());
+  return MST_OK;
+}
+
+}  // extern "C"

@@ -39,6 +39,23 @@ def info_nce_rows(all_emb, all_labels, row0, rows, temperature):
     return torch.where(keep, li, torch.zeros_like(li)).sum(), keep.sum()
 
 
+def info_nce_rows_hip(all_emb, all_labels, row0, rows, temperature):
+    """Same as info_nce_rows, in one libmst.so launch pair (`mst_infonce_forward`); forward only."""
+    import ctypes as C
+    from . import _lib
+    e = all_emb.detach().contiguous().float()
+    lab = all_labels.contiguous().to(torch.int64)
+    N, D = e.shape
+    L = _lib.lib()
+    need = L.mst_infonce_workspace_bytes(N, D)
+    ws = torch.empty(need, dtype=torch.uint8, device=e.device)
+    out = torch.empty(2, dtype=torch.float32, device=e.device)
+    with torch.cuda.device(e.device):
+        _lib.check(L.mst_infonce_forward(_lib.dptr(e), _lib.dptr(lab), N, D, row0, rows, float(temperature), _lib.dptr(out),
+                                         _lib.dptr(ws), need, _lib.stream_ptr(e.device)), "mst_infonce_forward")
+    return out[0], out[1]
+
+
 class InfoNCELoss(nn.Module):
     """Drop-in for reference InfoNCELoss(temperature)(embeddings (N, D), song_labels (N,)) -> scalar."""
 
@@ -51,7 +68,8 @@ class InfoNCELoss(nn.Module):
         if self.gather:
             import torch.distributed as dist
             all_e, all_l, row0 = gather_embeddings(embeddings, song_labels)
-            s, c = info_nce_rows(all_e, all_l, row0, embeddings.shape[0], self.temperature)
+            rows_fn = info_nce_rows if (all_e.requires_grad or not all_e.is_cuda) else info_nce_rows_hip
+            s, c = rows_fn(all_e, all_l, row0, embeddings.shape[0], self.temperature)
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 sc = torch.stack([s.detach(), c.to(s.dtype)])
                 dist.all_reduce(sc)
@@ -60,7 +78,8 @@ class InfoNCELoss(nn.Module):
                 # mean over all valid anchors of the global batch; gradient of the local share
                 return s / sc[1] * dist.get_world_size() if s.requires_grad else sc[0] / sc[1]
         else:
-            s, c = info_nce_rows(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
+            rows_fn = info_nce_rows if (embeddings.requires_grad or not embeddings.is_cuda) else info_nce_rows_hip
+            s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
         if c.item() == 0:
             raise RuntimeError(
                 f"No positive pairs found in batch! Batch size: {embeddings.shape[0]}, "

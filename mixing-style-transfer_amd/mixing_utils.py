@@ -203,3 +203,148 @@ class MixingFeatureExtractor:
         f = self.extract_all_features(stems_dict)
         sd = 5 if not self.use_detailed_spectral else self.n_spectral_bins + 2
         return f[2 * (10 + sd):2 * (10 + sd) + 4]
+
+
+# =============================================================================
+# Audio augmentations (degradations)
+# =============================================================================
+
+class AudioAugmenter:
+    """Apply mixing degradation augmentations to separated stems (reference src/mixing_utils.py:364-479).
+
+    Every random decision is drawn on the host from the global torch CPU generator in exactly the reference's
+    order -- per stem [coin, (gain)] [coin, (hi/lo coin)] [coin] [coin, (cutoff)], then [coin, (randn(L))] -- so a
+    seeded run makes bit-identical decisions; the audio is then processed by libmst.so (`mst_aug_apply`).
+    `augment_stems` accepts the reference's {stem: (2, T)} dict or a batched {stem: (B, 2, T)} dict (clips are drawn
+    one after the other, as consecutive reference calls would).  `last_trace` keeps the decisions of the last call.
+    """
+
+    def __init__(self, sample_rate=44100, gain_range=9.0, prob=0.5):
+        self.sr = sample_rate
+        self.gain_range = gain_range
+        self.prob = prob
+        self._sos_cache = {}
+        self._ws = None
+        self.last_trace = None
+
+    # -- host side: decisions ------------------------------------------------------------------
+    def _butter(self, order, fc, btype):
+        from scipy.signal import butter
+        key = (order, float(fc), btype)
+        if key not in self._sos_cache:
+            if len(self._sos_cache) > 64:
+                self._sos_cache.clear()
+            self._sos_cache[key] = np.ascontiguousarray(butter(order, fc, btype=btype, fs=self.sr, output="sos"),
+                                                        dtype=np.float64)
+        return self._sos_cache[key]
+
+    def _draw_tilt(self, st, tr):
+        hi = bool(torch.rand(1) < 0.5)
+        sos = self._butter(2, 2000, "high") if hi else self._butter(2, 500, "low")
+        st.tilt = 1
+        st.tilt_sos[:] = sos[0].tolist()
+        tr["tilt"] = "high" if hi else "low"
+
+    def _draw_bw(self, st, tr):
+        cutoff = torch.rand(1) * 8000 + 4000
+        sos = self._butter(4, cutoff.item(), "low")
+        st.bw_sections = sos.shape[0]
+        st.bw_sos[:] = sos.reshape(-1).tolist()
+        tr["cutoff"] = cutoff.item()
+
+    def _make_ir(self, decay=0.5):
+        n = int(self.sr * decay)
+        t = torch.linspace(0, decay, n)
+        return torch.exp(-t / (decay / 4)) * torch.randn(n) * 0.1
+
+    def _draw_clip(self, clip):
+        trace = {}
+        for i, name in enumerate(STEMS):
+            st, tr = clip.stem[i], {}
+            st.gain = 1.0
+            if torch.rand(1) < self.prob:
+                gain_db = torch.rand(1) * 2 * self.gain_range - self.gain_range
+                st.gain = (10 ** (gain_db / 20)).item()
+                tr["gain_db"] = gain_db.item()
+            if torch.rand(1) < self.prob:
+                self._draw_tilt(st, tr)
+            if torch.rand(1) < self.prob:
+                st.compress = 1
+                tr["comp"] = True
+            if torch.rand(1) < self.prob:
+                self._draw_bw(st, tr)
+            trace[name] = tr
+        ir = None
+        if torch.rand(1) < self.prob:
+            clip.reverb = 1
+            ir = self._make_ir()
+            trace["reverb_ir"] = ir
+        return ir, trace
+
+    # -- device side ---------------------------------------------------------------------------
+    def _apply(self, x8, clips, irs):
+        """x8 (B, 8, T) fp32 CUDA contiguous, modified in place."""
+        if not x8.is_cuda:
+            raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
+        B, _, T = x8.shape
+        L = _lib.lib()
+        ir_len = max([0] + [ir.numel() for ir in irs if ir is not None])
+        ir_dev = None
+        if ir_len:
+            host = torch.zeros(B, ir_len)
+            for b, ir in enumerate(irs):
+                if ir is not None:
+                    host[b] = ir
+            ir_dev = host.to(x8.device)
+        need = L.mst_aug_workspace_bytes(B, T, ir_len)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x8.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x8.device)
+        with torch.cuda.device(x8.device):
+            _lib.check(L.mst_aug_apply(clips, B, T, _lib.dptr(x8), _lib.dptr(ir_dev), ir_len, _lib.dptr(self._ws), need,
+                                       _lib.stream_ptr(x8.device)), "mst_aug_apply")
+        return x8
+
+    def augment_stems(self, stems_dict):
+        batched = next(iter(stems_dict.values())).dim() == 3
+        x8 = stems_to_tensor(stems_dict).float().contiguous()     # the reference's `.clone()`
+        if x8.data_ptr() == next(iter(stems_dict.values())).data_ptr():
+            x8 = x8.clone()
+        B = x8.shape[0]
+        clips = (_lib.AugClip * B)()
+        irs, traces = [], []
+        for b in range(B):
+            ir, tr = self._draw_clip(clips[b])
+            irs.append(ir)
+            traces.append(tr)
+        self.last_trace = traces if batched else traces[0]
+        self._apply(x8, clips, irs)
+        out = {s: x8[:, 2 * i:2 * i + 2] for i, s in enumerate(STEMS)}
+        return out if batched else {s: v[0] for s, v in out.items()}
+
+    def _single(self, audio, fill):
+        """Run one effect on a (2, T) tensor: it rides as the first stem of an otherwise silent clip."""
+        x8 = torch.zeros(1, 8, audio.shape[-1], dtype=torch.float32, device=audio.device)
+        x8[0, 0:2] = audio
+        clips = (_lib.AugClip * 1)()
+        for i in range(4):
+            clips[0].stem[i].gain = 1.0
+        ir = fill(clips[0])
+        self._apply(x8, clips, [ir])
+        return x8[0, 0:2]
+
+    def apply_spectral_tilt(self, audio):
+        return self._single(audio, lambda c: self._draw_tilt(c.stem[0], {}))
+
+    def apply_compression(self, audio, threshold=-20, ratio=4):
+        if threshold != -20 or ratio != 4:
+            raise NotImplementedError("the HIP compressor implements the reference's fixed -20 dB / 4:1 setting")
+        return self._single(audio, lambda c: setattr(c.stem[0], "compress", 1))
+
+    def apply_bandwidth_limit(self, audio):
+        return self._single(audio, lambda c: self._draw_bw(c.stem[0], {}))
+
+    def apply_reverb(self, audio, decay=0.5):
+        def fill(c):
+            c.reverb = 2   # plain reverb of the first stem: 0.7 * x + 0.3 * xcorr(x, ir)
+            return self._make_ir(decay)
+        return self._single(audio, fill)
