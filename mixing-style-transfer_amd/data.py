@@ -1,0 +1,201 @@
+"""MI355X mirror of reference src/data.py (contrastive part): SCNetSeparator, FMABaselineDataset,
+baseline_collate_fn -- same signatures, return tuples and exceptions.
+
+Differences forced by the device path:
+  * `compute_features`: the reference computes the 64-d features inside the (fork'd) DataLoader worker on the CPU
+    (src/data.py:231-265).  A HIP context cannot be used after fork, so with the default `compute_features="auto"`
+    the worker returns `None` placeholders when it has no GPU context and the features are produced per batch on
+    the device (`MixingFeatureExtractor.features_and_logmel`).  `compute_features=True` computes them in
+    `__getitem__` on the GPU (main process / spawn workers only).
+  * stem decoding: the reference reads `{stem}.mp3` with torchaudio.load (not installed here).  Decoding stays a
+    host concern: `stem_loader` is a pluggable callable `path -> (tensor (C, L), sample_rate)`;
+    the default tries torchaudio, then a PCM `.wav` reader for pre-decoded stems.
+SCNet source and weights are not part of the reference tree (un-vendored submodule): `SCNetSeparator` is
+the interface only and needs a user-registered backend.
+"""
+import glob
+import os
+import wave
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .mixing_utils import STEMS, MixingFeatureExtractor
+
+_SEPARATOR_BACKEND = None
+
+
+def register_separator_backend(factory):
+    """factory(model_path, config_path, device) -> object with .separate(np.ndarray (2,T)) -> {stem: np.ndarray (2,T)}"""
+    global _SEPARATOR_BACKEND
+    _SEPARATOR_BACKEND = factory
+
+
+class SCNetSeparator:
+    """Wrapper for SCNet source separation (reference src/data.py:28-108): audio (2,T)|(T,) -> 4 stems (2,T) float CPU."""
+
+    def __init__(self, model_path, config_path, device="cuda"):
+        if _SEPARATOR_BACKEND is None:
+            raise RuntimeError(
+                "SCNetSeparator: the SCNet implementation (ZFTurbo/Music-Source-Separation-Training) and its checkpoint "
+                "are not part of the reference tree (empty submodule); register a backend with "
+                "mst_amd.data.register_separator_backend(factory) or use pre-separated stems (FMABaselineDataset).")
+        self.device = device
+        self._impl = _SEPARATOR_BACKEND(model_path, config_path, device)
+        self.sample_rate = getattr(self._impl, "sample_rate", 44100)
+
+    @torch.no_grad()
+    def separate(self, audio):
+        if isinstance(audio, torch.Tensor):
+            audio = audio.cpu().numpy()
+        if audio.ndim == 1:
+            audio = np.stack([audio, audio], axis=0)
+        out = self._impl.separate(audio)
+        return {s: torch.from_numpy(np.asarray(out[s])).float() for s in STEMS}
+
+
+def _load_wav(path):
+    with wave.open(path, "rb") as w:
+        ch, sw, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    if sw == 2:
+        a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif sw == 4:
+        a = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    else:
+        raise ValueError(f"unsupported PCM width {sw} in {path}")
+    return torch.from_numpy(a.reshape(-1, ch).T.copy()), sr
+
+
+def default_stem_loader(path):
+    try:
+        import torchaudio  # noqa: F401
+        return torchaudio.load(path)
+    except ImportError:
+        if path.lower().endswith(".wav"):
+            return _load_wav(path)
+        raise RuntimeError(f"cannot decode {path}: torchaudio is not installed; pass stem_loader= or use .wav stems")
+
+
+class FMABaselineDataset(Dataset):
+    """Pre-separated stems, positive pairs = different temporal segments of one song (reference src/data.py:111-288)."""
+
+    def __init__(self, separated_path="/nas/FMA/fma_separated/", clip_duration=10.0, sample_rate=44100, n_fft=1024,
+                 hop_length=256, n_mels=128, num_segments=2, min_audio_duration=25.0, compute_features="auto",
+                 stem_loader=None, stem_ext=".mp3", device=None):
+        self.separated_path = separated_path
+        self.clip_duration = clip_duration
+        self.sr = sample_rate
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.n_mels = n_mels
+        self.clip_samples = int(clip_duration * sample_rate)
+        self.num_segments = num_segments
+        self.min_duration = min_audio_duration
+        self.compute_features = compute_features
+        self.stem_loader = stem_loader or default_stem_loader
+        self.stem_ext = stem_ext
+        self.device = device
+        if not os.path.exists(separated_path):
+            raise ValueError(f"Separated stems directory not found: {separated_path}")
+        self.track_dirs = [d for d in glob.glob(os.path.join(separated_path, "*")) if os.path.isdir(d)]
+        self.feature_extractor = MixingFeatureExtractor(sample_rate, n_fft, hop_length, n_mels)
+
+    def __len__(self):
+        return len(self.track_dirs)
+
+    def _load_single_stem(self, stem_path):
+        audio, sr = self.stem_loader(stem_path)
+        audio = audio.float()
+        if sr != self.sr:
+            try:
+                import torchaudio
+                audio = torchaudio.transforms.Resample(sr, self.sr)(audio)
+            except ImportError:
+                raise RuntimeError(f"{stem_path}: sample rate {sr} != {self.sr} and torchaudio (Resample) is not installed")
+        if audio.shape[0] == 1:
+            audio = audio.repeat(2, 1)
+        elif audio.shape[0] > 2:
+            audio = audio[:2, :]
+        return audio
+
+    def _load_stems(self, track_dir):
+        stems = {}
+        for name in STEMS:
+            path = os.path.join(track_dir, f"{name}{self.stem_ext}")
+            if not os.path.exists(path):
+                raise FileNotFoundError(
+                    f"Stem file not found: {path}\nTrack directory: {track_dir}\n"
+                    f"This indicates the pre-separated stems are missing or in wrong format.")
+            stems[name] = self._load_single_stem(path)
+        return stems
+
+    def _features(self, clip_stems):
+        mode = self.compute_features
+        if mode == "auto":
+            mode = torch.cuda.is_initialized() if torch.cuda.is_available() else False
+        if not mode:
+            return None
+        dev = self.device or "cuda"
+        return self.feature_extractor.extract_all_features({k: v.to(dev) for k, v in clip_stems.items()}).cpu()
+
+    def _crop_starts(self, audio_length):
+        """numpy global-RNG draws in the reference's order (src/data.py:222-266)."""
+        C = self.clip_samples
+        if self.num_segments == 1:
+            m = audio_length - C
+            return [0 if m <= 0 else int(np.random.randint(0, m + 1))]
+        if self.num_segments == 2:
+            if audio_length < 2 * C:
+                return [0, 0]
+            s1 = int(np.random.randint(0, audio_length - 2 * C + 1))
+            s2 = int(np.random.randint(s1 + C, audio_length - C + 1))
+            return [s1, s2]
+        raise ValueError(f"num_segments={self.num_segments} is not supported. "
+                         f"Only num_segments=1 or num_segments=2 are implemented.")
+
+    def __getitem__(self, idx):
+        track_dir = self.track_dirs[idx]
+        if self.num_segments not in (1, 2):
+            self._crop_starts(0)  # raises the reference's ValueError
+        stems_full = self._load_stems(track_dir)
+        audio_length = stems_full["vocals"].shape[1]
+        stems_list, features_list = [], []
+        for start in self._crop_starts(audio_length):
+            clip = self._extract_clip(stems_full, start, audio_length)
+            stems_list.append(clip)
+            features_list.append(self._features(clip))
+        return stems_list, features_list, idx, track_dir
+
+    def _extract_clip(self, stems_full, start_idx, audio_length):
+        out = {}
+        for name, audio in stems_full.items():
+            seg = audio[:, start_idx:start_idx + self.clip_samples]
+            if seg.shape[1] < self.clip_samples:
+                seg = torch.nn.functional.pad(seg, (0, self.clip_samples - seg.shape[1]))
+            out[name] = seg
+        return out
+
+
+def baseline_collate_fn(batch):
+    """List of (stems_list, features_list, song_idx, track_dir) -> (stems_dict {stem: (N,2,T)}, features (N,F) or None
+    when the features are deferred to the device, song_labels (N,) int64, track_dirs [N]).  reference src/data.py:291-328"""
+    stems, feats, labels, dirs = [], [], [], []
+    for stems_list, features_list, song_idx, track_dir in batch:
+        for s, f in zip(stems_list, features_list):
+            stems.append(s)
+            feats.append(f)
+            labels.append(song_idx)
+            dirs.append(track_dir)
+    stems_dict = {name: torch.stack([s[name] for s in stems], dim=0) for name in STEMS}
+    features = None if any(f is None for f in feats) else torch.stack(feats, dim=0)
+    return stems_dict, features, torch.tensor(labels, dtype=torch.long), dirs
+
+
+def shard_batch(stems_dict, features, song_labels, rank, world_size):
+    """Clip-shard a collated batch across ranks: rank r gets clips [r*N/W, (r+1)*N/W)."""
+    n = song_labels.shape[0]
+    lo, hi = rank * n // world_size, (rank + 1) * n // world_size
+    return ({k: v[lo:hi] for k, v in stems_dict.items()}, None if features is None else features[lo:hi],
+            song_labels[lo:hi])

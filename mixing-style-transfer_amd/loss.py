@@ -6,20 +6,41 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _AllGatherWithGrad(torch.autograd.Function):
+    """all-gather whose backward all-reduces the gradient of the gathered tensor and returns the local slice, so the
+    gradient w.r.t. the local embeddings includes the terms where they act as *columns* of other ranks' anchors."""
+
+    @staticmethod
+    def forward(ctx, x):
+        import torch.distributed as dist
+        ws, ctx.rank, ctx.n = dist.get_world_size(), dist.get_rank(), x.shape[0]
+        out = torch.empty(ws * ctx.n, *x.shape[1:], dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.contiguous().clone()
+        dist.all_reduce(g)
+        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n]
+
+
 def gather_embeddings(emb: torch.Tensor, labels: torch.Tensor):
-    """All-gather (N_local, D) fp32 embeddings + (N_local,) int64 labels -> global tensors, rank order.
-    Gradient flows to the local slice only (the other slices are constants on this rank)."""
+    """All-gather (N_local, D) fp32 embeddings + (N_local,) int64 labels over RCCL/xGMI -> global tensors in rank
+    order, plus the row offset of the local slice.  Differentiable w.r.t. `emb` (see _AllGatherWithGrad)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return emb, labels, 0
     ws, rank = dist.get_world_size(), dist.get_rank()
     n = emb.shape[0]
-    all_e = torch.empty(ws * n, emb.shape[1], dtype=emb.dtype, device=emb.device)
     all_l = torch.empty(ws * n, dtype=labels.dtype, device=labels.device)
-    dist.all_gather_into_tensor(all_e, emb.detach().contiguous())
     dist.all_gather_into_tensor(all_l, labels.contiguous())
     if emb.requires_grad:
-        all_e = torch.cat([all_e[:rank * n], emb, all_e[(rank + 1) * n:]], 0)
+        all_e = _AllGatherWithGrad.apply(emb)
+    else:
+        all_e = torch.empty(ws * n, emb.shape[1], dtype=emb.dtype, device=emb.device)
+        dist.all_gather_into_tensor(all_e, emb.contiguous())
     return all_e, all_l, rank * n
 
 
@@ -75,8 +96,10 @@ class InfoNCELoss(nn.Module):
                 dist.all_reduce(sc)
                 if sc[1].item() == 0:
                     raise RuntimeError("No positive pairs found in batch!")
-                # mean over all valid anchors of the global batch; gradient of the local share
-                return s / sc[1] * dist.get_world_size() if s.requires_grad else sc[0] / sc[1]
+                # value: the global mean over all valid anchors (identical on every rank); gradient: this rank's share
+                # s / C_global -- summed over ranks (all-reduce SUM of parameter grads) it is the exact global gradient.
+                share = s / sc[1]
+                return share + (sc[0] / sc[1] - share).detach() if s.requires_grad else sc[0] / sc[1]
         else:
             rows_fn = info_nce_rows if (embeddings.requires_grad or not embeddings.is_cuda) else info_nce_rows_hip
             s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)

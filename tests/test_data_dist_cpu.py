@@ -1,0 +1,124 @@
+"""CPU: Dataset / collate host logic vs the oracle restatement, and the N>1 exchange path (world_size 2, gloo)."""
+import os
+import wave
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import cases
+from oracle import dataset as odata
+from oracle import loss as oloss
+
+
+def write_wav(path, x, sr=44100):
+    a = (x.clamp(-1, 1).T.numpy() * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(x.shape[0]); w.setsampwidth(2); w.setframerate(sr)
+        w.writeframes(a.tobytes())
+
+
+@pytest.fixture(scope="module")
+def stem_dir(tmp_path_factory):
+    root = tmp_path_factory.mktemp("sep")
+    lens = {"long": 9000, "short": 5000, "mono": 9000}
+    for name, L in lens.items():
+        d = root / name
+        d.mkdir()
+        x = cases.synth_clip(len(name), L, 4000)
+        for i, s in enumerate(cases.STEMS):
+            write_wav(str(d / f"{s}.wav"), x[2 * i:2 * i + (1 if name == "mono" else 2)], 4000)
+    return str(root)
+
+
+def make_ds(stem_dir, **kw):
+    from mst_amd.data import FMABaselineDataset
+    return FMABaselineDataset(stem_dir, clip_duration=1.0, sample_rate=4000, stem_ext=".wav", compute_features=False, **kw)
+
+
+def test_dataset_matches_oracle_crops_and_collate(stem_dir):
+    from mst_amd.data import baseline_collate_fn
+    ds = make_ds(stem_dir)
+    assert len(ds) == 3 and ds.clip_samples == 4000
+    np.random.seed(42)
+    items = [ds[i] for i in range(len(ds))]
+    np.random.seed(42)
+    for (stems_list, feats_list, idx, tdir) in items:
+        L = 5000 if tdir.endswith("short") else 9000
+        starts = odata.crop_starts(L, 4000, 2)
+        assert len(stems_list) == 2 and feats_list == [None, None]
+        full = ds._load_stems(tdir)
+        for clip, st in zip(stems_list, starts):
+            ref = odata.extract_clip(full, st, 4000)
+            for s in cases.STEMS:
+                assert clip[s].shape == (2, 4000) and torch.equal(clip[s], ref[s])
+        if tdir.endswith("short"):          # audio shorter than 2 clips: both start at 0 (src/data.py:241-248)
+            assert starts == [0, 0] and torch.equal(stems_list[0]["bass"], stems_list[1]["bass"])
+        if tdir.endswith("mono"):           # mono stems are duplicated to stereo (src/data.py:178-180)
+            assert torch.equal(stems_list[0]["drums"][0], stems_list[0]["drums"][1])
+    sd, feats, labels, dirs = baseline_collate_fn(items)
+    osd, _, olabels, odirs = odata.collate([(a, [torch.zeros(1)] * 2, c, d) for a, b, c, d in items])
+    assert feats is None and torch.equal(labels, olabels) and dirs == odirs and labels.dtype == torch.int64
+    for s in cases.STEMS:
+        assert sd[s].shape == (6, 2, 4000) and torch.equal(sd[s], osd[s])
+
+
+def test_dataset_single_segment_padding_and_errors(stem_dir, tmp_path):
+    from mst_amd.data import FMABaselineDataset, SCNetSeparator
+    ds = make_ds(stem_dir, num_segments=1)
+    ds.clip_samples = 6000                      # longer than the 'short' track -> zero padded tail (src/data.py:283-287)
+    i = [k for k, d in enumerate(ds.track_dirs) if d.endswith("short")][0]
+    stems_list, _, _, _ = ds[i]
+    assert stems_list[0]["other"].shape == (2, 6000) and not stems_list[0]["other"][:, 5000:].any()
+    with pytest.raises(ValueError):
+        FMABaselineDataset(str(tmp_path / "nope"))
+    with pytest.raises(ValueError):
+        make_ds(stem_dir, num_segments=3)[0]
+    os.makedirs(tmp_path / "sep2" / "t0")
+    with pytest.raises(FileNotFoundError):
+        FMABaselineDataset(str(tmp_path / "sep2"), stem_ext=".wav")[0]
+    with pytest.raises(RuntimeError):
+        SCNetSeparator("model.ckpt", "config.yaml")
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mst_amd.data import shard_batch
+        from mst_amd.loss import InfoNCELoss, gather_embeddings
+        g = torch.Generator().manual_seed(11)
+        emb = torch.randn(12, 32, generator=g)
+        labels = torch.arange(12) // 2          # pairs: both segments of a song are adjacent
+        stems = {s: torch.arange(12.0)[:, None, None].repeat(1, 2, 8) for s in cases.STEMS}
+        sd, _, lab = shard_batch(stems, None, labels, rank, world)
+        lo = rank * 12 // world
+        assert sd["bass"].shape[0] == 12 // world and sd["bass"][0, 0, 0].item() == lo
+        local = emb[lo:lo + 12 // world].clone().requires_grad_(True)
+        all_e, all_l, row0 = gather_embeddings(local, lab)
+        assert row0 == lo and torch.equal(all_l, labels) and torch.allclose(all_e.detach(), emb)
+        loss = InfoNCELoss(0.1, gather=True)(local, lab)
+        loss.backward()
+        # reference on the un-sharded batch
+        full = emb.clone().requires_grad_(True)
+        ref = oloss.info_nce(full, labels, 0.1)
+        ref.backward()
+        # every rank returns the global loss; gathered local gradients == gradient of the un-sharded reference loss
+        gl = [torch.zeros(12 // world, 32) for _ in range(world)]
+        dist.all_gather(gl, local.grad)
+        ret[rank] = (abs(loss.item() - ref.item()) < 1e-5 and torch.allclose(torch.cat(gl), full.grad, atol=1e-6))
+        # forward-only (no grad): identical scalar on every rank
+        v = InfoNCELoss(0.1, gather=True)(local.detach(), lab)
+        ret[rank] = ret[rank] and abs(v.item() - ref.item()) < 1e-5
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_gather_infonce_world2_gloo():
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
