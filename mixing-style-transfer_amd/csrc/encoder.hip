@@ -135,7 +135,7 @@ struct CC<2, SUB> {  // Conv2d(32 -> 64, 7x7, pad 3) + MaxPool2d((4, 4)); wave t
 
 struct ConvParams {
   const float* in;
-  const float* wfrag;  // [nsub][NCH][WCHP]   B fragments: [tap][nt][lane]
+  const float* wfrag;  // [nsub][NCH][WBP]   B fragments: [tap][nt][lane], zero padded to the chunk pitch
   const float2* aff;   // [B][nsub][COUT]
   float* out;
   int B, nsub;
@@ -152,19 +152,30 @@ struct Tile {
   int valid, clip, band, tr, tc;
 };
 
+
+template <int LAYER, int SUB>
+struct ConvGeom {
+  using C = CC<LAYER, SUB>;
+  static constexpr int WCH = 49 * C::NT * 64;                                   // floats per weight chunk
+  static constexpr int NWF = (WCH / 4 + kConvThreads - 1) / kConvThreads;      // float4 weight prefetches per thread
+  static constexpr int WBP = NWF * kConvThreads * 4;                            // chunk pitch (floats), global and LDS
+  static constexpr int PATCH = (4 * C::PR * C::PC + 3) / 4 * 4;                 // floats per wave patch
+  static constexpr int NPF = (4 * C::PR * C::RL + 63) / 64;                     // patch prefetches per lane
+  static constexpr int NCV = C::RL >= 64 ? C::RL / 64 : 1;                      // column variants of the loader
+};
+
 template <int LAYER, int SUB>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) {
   using C = CC<LAYER, SUB>;
+  using GEO = ConvGeom<LAYER, SUB>;
   constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
-  constexpr int WCH = 49 * NT * 64;                   // floats per weight chunk
-  constexpr int WCHP = (WCH + 255) / 256 * 256;       // padded chunk pitch
-  constexpr int PATCH = (4 * PR * PC + 3) / 4 * 4;    // floats per wave patch
-  constexpr int NWF = (WCH / 4 + kConvThreads - 1) / kConvThreads;  // float4 weight prefetches per thread
-  constexpr int NPF = (4 * PR * RL + 63) / 64;                       // patch prefetches per lane
+  constexpr int WBP = GEO::WBP, PATCH = GEO::PATCH, NWF = GEO::NWF, NPF = GEO::NPF, NCV = GEO::NCV;
+  constexpr int NPIECE = NPF + NWF, PPT = (NPIECE + 48) / 49;  // prefetch pieces, pieces issued per tap
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* wbuf = smem;                                  // [2][WCHP]
-  float* pbuf = smem + 2 * WCHP + wave * PATCH;        // wave-private patch [4][PR][PC]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile bookkeeping stays on the SALU
+  float* wbuf = smem;                                  // [2][WBP]
+  float* pbuf = smem + 2 * WBP + wave * PATCH;         // wave-private patch [4][PR][PC]
 
   const int G = gridDim.x;
   const int wg = mst::xcd_remap(blockIdx.x, G);
@@ -173,14 +184,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
   const int nq = my_sets * NCH;
   const int tpb = p.tiles_r * p.tiles_c;
 
-  auto decode = [&](int q) {
+  auto decode = [&](int q) __attribute__((always_inline)) {
     const int s = wg + (q / NCH) * G;
     Tile t;
-    t.band = s / p.sets_per_band;
+    t.band = min(s / p.sets_per_band, p.nsub - 1);
     const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
-    t.valid = idx < p.B * tpb;
-    t.clip = idx / tpb;
-    const int ti = idx - t.clip * tpb;
+    t.valid = (q < nq) && idx < p.B * tpb;
+    t.clip = t.valid ? idx / tpb : 0;
+    const int ti = t.valid ? idx - t.clip * tpb : 0;
     t.tc = ti / p.tiles_r;
     t.tr = ti - t.tc * p.tiles_r;
     return t;
@@ -204,57 +215,86 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     abase[t] = kq * (PR * PC) + dr * PC + wc;
   }
 
-  float4 wreg[NWF];
+  // ---- prefetch state of the NEXT chunk: branch-free loads at clamped addresses, masked when staged into LDS
+  f32x4 wreg[NWF];
   float pf[NPF];
-  auto prefetch = [&](int q, const Tile& t) {
+  unsigned long long rowmask = 0;   // RL >= 64: bit i = row of piece i is inside the image (wave-uniform)
+  unsigned colmask = 0;             // RL >= 64: bit j = column variant j of this lane is inside; RL == 16: bit i = piece i
+  int coff[NCV];                    // clamped column offsets of this lane
+  const float* nsrc = p.in;         // wave-uniform base of the next tile's 4-channel slab
+  const f32x4* nwsrc = reinterpret_cast<const f32x4*>(p.wfrag);
+  int nrow0 = 0, ncol0 = 0, nvalid = 0;
+
+  auto prefetch_setup = [&](int q, const Tile& t) __attribute__((always_inline)) {
     const int chunk = q % NCH;
-    const float4* wsrc = reinterpret_cast<const float4*>(p.wfrag + ((size_t)t.band * NCH + chunk) * WCHP);
+    nwsrc = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)t.band * NCH + chunk) * WBP);
+    nrow0 = (LAYER == 1 ? C::TROWS * t.tr : 8 * t.tr) - 3;
+    ncol0 = C::TCOLS * t.tc - 3;
+    nvalid = t.valid;
+    nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff + (size_t)(4 * chunk) * p.in_cstride;
+    rowmask = 0, colmask = 0;
+    if constexpr (RL >= 64) {
 #pragma unroll
-    for (int i = 0; i < NWF; ++i) {
-      const int k = tid + kConvThreads * i;
-      wreg[i] = (k < WCH / 4) ? wsrc[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < NCV; ++j) {
+        const int col = lane + 64 * j, cin = ncol0 + col;
+        if (col < PC && cin >= 0 && cin < p.in_cols) colmask |= 1u << j;
+        coff[j] = min(max(cin, 0), p.in_cols - 1);
+      }
     }
-    const int row0 = (LAYER == 1 ? C::TROWS * t.tr : 8 * t.tr) - 3;
-    const int col0 = C::TCOLS * t.tc - 3;
-    const float* src = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff +
-                       (size_t)(4 * chunk) * p.in_cstride;
-#pragma unroll
-    for (int i = 0; i < NPF; ++i) {
-      const int e = lane + 64 * i;
-      const int row = e / RL, col = e % RL;  // row = cc * PR + r
-      const int cc = row / PR, r = row - cc * PR;
-      const int rin = row0 + r, cin = col0 + col;
-      const bool ok = t.valid && row < 4 * PR && col < PC && rin >= 0 && rin < p.in_rows && cin >= 0 && cin < p.in_cols;
-      pf[i] = ok ? src[(size_t)cc * p.in_cstride + (size_t)rin * p.in_cols + cin] : 0.f;
+  };
+  auto prefetch_piece = [&](int i) __attribute__((always_inline)) {  // i is a compile-time constant after unrolling
+    if (i < NPF) {
+      if constexpr (RL >= 64) {
+        const int row = i / NCV, j = i % NCV;
+        const int cc = row / PR, r = row % PR;
+        const int rin = nrow0 + r;
+        const int rc = min(max(rin, 0), p.in_rows - 1);
+        if (nvalid && rin == rc) rowmask |= 1ull << i;
+        const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols;  // wave-uniform
+        pf[i] = rowp[coff[j]];
+      } else {
+        const int e = lane + 64 * i;
+        const int row = e / RL, col = e % RL;
+        const int cc = min(row / PR, 3), r = row % PR;
+        const int rin = nrow0 + r, cin = ncol0 + col;
+        const int rc = min(max(rin, 0), p.in_rows - 1), cl = min(max(cin, 0), p.in_cols - 1);
+        if (nvalid && row < 4 * PR && col < PC && rin == rc && cin == cl) colmask |= 1u << i;
+        pf[i] = nsrc[cc * p.in_cstride + rc * p.in_cols + cl];
+      }
+    } else if (i < NPIECE) {
+      wreg[i - NPF] = nwsrc[tid + kConvThreads * (i - NPF)];
     }
   };
 
   f32x4 acc[MT][NT];
   Tile cur{}, nxt{};
+  nxt = decode(0);
   if (nq > 0) {
-    nxt = decode(0);
-    prefetch(0, nxt);
+    prefetch_setup(0, nxt);
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) prefetch_piece(i);
   }
   for (int q = 0; q < nq; ++q) {
-    float* wb = wbuf + (q & 1) * WCHP;
-    // stage the prefetched chunk into LDS
+    float* wb = wbuf + (q & 1) * WBP;
+    // stage the prefetched chunk into LDS (unconditional stores; out-of-image elements become zeros)
 #pragma unroll
-    for (int i = 0; i < NWF; ++i) {
-      const int k = tid + kConvThreads * i;
-      if (k < WCH / 4) reinterpret_cast<float4*>(wb)[k] = wreg[i];
-    }
+    for (int i = 0; i < NWF; ++i) reinterpret_cast<f32x4*>(wb)[tid + kConvThreads * i] = wreg[i];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
-      const int e = lane + 64 * i;
-      const int row = e / RL, col = e % RL;
-      if (row < 4 * PR && col < PC) pbuf[row * PC + col] = pf[i];
+      if constexpr (RL >= 64) {
+        const int row = i / NCV, j = i % NCV, col = lane + 64 * j;
+        const bool ok = ((rowmask >> i) & 1ull) && ((colmask >> j) & 1u);
+        if (col < PC) pbuf[row * PC + col] = ok ? pf[i] : 0.f;
+      } else {
+        const int e = lane + 64 * i;
+        const int row = e / RL, col = e % RL;
+        if (row < 4 * PR && col < PC) pbuf[row * PC + col] = ((colmask >> i) & 1u) ? pf[i] : 0.f;
+      }
     }
     __syncthreads();
     cur = nxt;
-    if (q + 1 < nq) {
-      nxt = decode(q + 1);
-      prefetch(q + 1, nxt);
-    }
+    nxt = decode(q + 1);
+    prefetch_setup(q + 1, nxt);   // past the end this re-reads valid memory and is never staged
     const int chunk = q % NCH;
     if (chunk == 0) {
 #pragma unroll
@@ -262,19 +302,32 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // 49 taps x (MT A-fragments, NT B-fragments, MT*NT MFMAs)
+    // 49 taps x (MT A-fragments, NT B-fragments, MT*NT MFMAs); the fragments of tap+1 are read from LDS and PPT
+    // pieces of the next chunk are fetched from global memory while the MFMAs of this tap are in flight
+    {
+      float a[2][MT], b[2][NT];
 #pragma unroll
-    for (int tap = 0; tap < 49; ++tap) {
-      const int off = (tap / 7) * PC + (tap % 7);
-      float a[MT], b[NT];
+      for (int t = 0; t < MT; ++t) a[0][t] = pbuf[abase[t]];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a[t] = pbuf[abase[t] + off];
+      for (int n = 0; n < NT; ++n) b[0][n] = wb[n * 64 + lane];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = wb[(tap * NT + n) * 64 + lane];
+      for (int tap = 0; tap < 49; ++tap) {
+        const int cu = tap & 1, nx = cu ^ 1;
+        const int off = ((tap + 1) / 7) * PC + ((tap + 1) % 7);
+        // hand-interleaved issue order, pinned by sched_barrier: after every MFMA one LDS read of the next tap's
+        // fragments (or a global prefetch load of the next chunk) is issued into the shadow of that MFMA
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n], acc[t][n], 0, 0, 0);
+        for (int i = 0; i < MT * NT; ++i) {
+          const int t = i / NT, n = i % NT;
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+          if (tap + 1 < 49) {
+            if (i < NT) b[nx][i] = wb[((tap + 1) * NT + i) * 64 + lane];   // B first: needed by the next tap's MFMA 0
+            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
+          }
+          if (i >= MT + NT && i - (MT + NT) < PPT) prefetch_piece(tap * PPT + (i - (MT + NT)));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     if (chunk == NCH - 1 && cur.valid) {
       // epilogue: y = A*acc + C, ReLU, max over the window, all in this lane's registers
@@ -307,6 +360,164 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
           if (pr < p.out_rows && pc < p.out_cols)  // pool_in[clip][(band*64 + ch)*FD + pr][pc]
             p.out[(((size_t)cur.clip * p.nsub + cur.band) * C::COUT + ch) * p.out_rows * p.out_cols +
                   (size_t)pr * p.out_cols + pc] = m;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 with band-resident weights (SUB == 2, the reference default 20-mel sub-bands).
+// All 392 x 32 weights of one sub-band (50 KB) stay in LDS next to eight wave-private 8-channel patches
+// (8 x 11.8 KB): there is NO per-tile barrier.  Every wave free-runs over its own tiles, so the staging / epilogue
+// of one wave overlaps the MFMAs of its SIMD partner.  Workgroups own contiguous runs of sets, so the band (and
+// with it the LDS weight image) changes at most once per workgroup.
+// ------------------------------------------------------------------------------------------
+template <int SUB>
+__global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const ConvParams p) {
+  using C = CC<1, SUB>;
+  constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
+  static_assert(C::RL == 64, "resident conv1 expects one loader row per instruction");
+  constexpr int WCH = 49 * NT * 64;                  // floats per 4-channel weight chunk
+  constexpr int WBP = ConvGeom<1, SUB>::WBP;         // chunk pitch in global memory
+  constexpr int CHS = PR * PC;                       // floats per patch channel
+  constexpr int PATCH = 8 * CHS;                     // 8 input channels
+  constexpr int NPF = 8 * PR;                        // one 64-lane row load per (channel, row)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* wres = smem;                                // [2][WCH]
+  float* pbuf = smem + 2 * WCH + wave * PATCH;
+
+  const int G = gridDim.x;
+  const int wg = mst::xcd_remap(blockIdx.x, G);
+  const int total_sets = p.nsub * p.sets_per_band;
+  const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
+  const int tpb = p.tiles_r * p.tiles_c;
+
+  auto decode = [&](int s) __attribute__((always_inline)) {
+    Tile t;
+    t.band = min(s / p.sets_per_band, p.nsub - 1);
+    const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
+    t.valid = (s < s_end) && idx < p.B * tpb;
+    t.clip = t.valid ? idx / tpb : 0;
+    const int ti = t.valid ? idx - t.clip * tpb : 0;
+    t.tc = ti / p.tiles_r;
+    t.tr = ti - t.tc * p.tiles_r;
+    return t;
+  };
+
+  const int kq = lane >> 4, ai = lane & 15, ag = ai >> 2, areg = ai & 3;
+  int abase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int e = 4 * t + areg, wv = e / C::WIN, pos = e % C::WIN;
+    abase[t] = kq * CHS + (pos / 5) * PC + 5 * (C::WPG * ag + wv) + pos % 5;
+  }
+
+  float pf[NPF];
+  unsigned long long rowmask = 0;
+  bool col_ok = false;
+  int coff = 0, nrow0 = 0, nvalid = 0;
+  const float* nsrc = p.in;
+  auto prefetch_setup = [&](const Tile& t) __attribute__((always_inline)) {
+    nrow0 = C::TROWS * t.tr - 3;
+    const int col0 = C::TCOLS * t.tc - 3, cin = col0 + lane;
+    nvalid = t.valid;
+    nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
+    col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
+    coff = min(max(cin, 0), p.in_cols - 1);
+    rowmask = 0;
+  };
+  auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
+    if (i < NPF) {
+      const int cc = i / PR, r = i % PR;
+      const int rin = nrow0 + r;
+      const int rc = min(max(rin, 0), p.in_rows - 1);
+      if (nvalid && rin == rc) rowmask |= 1ull << i;
+      const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols;
+      pf[i] = rowp[coff];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  int cur_band = -1;
+  Tile cur{}, nxt = decode(s_begin);
+  prefetch_setup(nxt);
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+
+  for (int s = s_begin; s < s_end; ++s) {
+    cur = nxt;
+    if (cur.band != cur_band) {  // same `s` sequence in every wave: all eight reach this together
+      __syncthreads();
+      for (int c = 0; c < 2; ++c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)cur.band * 2 + c) * WBP);
+        for (int k = tid; k < WCH / 4; k += kConvThreads) reinterpret_cast<f32x4*>(wres + c * WCH)[k] = src[k];
+      }
+      __syncthreads();
+      cur_band = cur.band;
+    }
+    // stage this wave's prefetched patch (wave-private: no barrier)
+#pragma unroll
+    for (int i = 0; i < NPF; ++i)
+      if (lane < PC) pbuf[i * PC + lane] = (((rowmask >> i) & 1ull) && col_ok) ? pf[i] : 0.f;
+    nxt = decode(s + 1);
+    prefetch_setup(nxt);
+    if (!cur.valid) {  // ragged tail of the band: nothing to compute, but keep the prefetch chain alive
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+      continue;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // 98 k-steps = 49 taps x 2 channel groups; fragments of step+1 are read while the MFMAs of step run, and one
+      // row of the NEXT tile's patch is fetched from global memory per step for the first 64 steps
+      float a[2][MT], b[2][NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[0][t] = pbuf[abase[t]];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[0][n] = wres[n * 64 + lane];
+#pragma unroll
+      for (int ks = 0; ks < 98; ++ks) {
+        const int cu = ks & 1, nx = cu ^ 1;
+        const int tap = (ks + 1) >> 1, ch = (ks + 1) & 1;
+        const int off = ch * 4 * CHS + (tap / 7) * PC + (tap % 7);
+#pragma unroll
+        for (int i = 0; i < MT * NT; ++i) {
+          const int t = i / NT, n = i % NT;
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+          if (ks + 1 < 98) {
+            if (i < NT) b[nx][i] = wres[ch * WCH + (tap * NT + i) * 64 + lane];
+            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
+          }
+          if (i == MT + NT) prefetch_piece(ks);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    {
+      const int j = lane & 15, g = lane >> 4;
+      const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
+      float* orow = p.out + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT * p.out_rows * p.out_cols +
+                    (size_t)cur.tr * p.out_cols;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = n * 16 + j;
+        const float2 ac = aff[ch];
+#pragma unroll
+        for (int wv = 0; wv < C::WPG; ++wv) {
+          float m = 0.f;
+#pragma unroll
+          for (int pos = 0; pos < C::WIN; ++pos) {
+            const int e = wv * C::WIN + pos;
+            m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
+          }
+          const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
+          if (pc < p.out_cols) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
         }
       }
     }
@@ -525,9 +736,8 @@ std::vector<float> transpose(const float* w, int rows, int cols) {  // [rows][co
 }
 
 // conv weights [nsub][COUT][CIN][7][7] -> [nsub][CIN/4][WCHP] with chunk layout [tap][nt][lane]
-std::vector<float> conv_fragments(const float* w, int nsub, int cout, int cin) {
+std::vector<float> conv_fragments(const float* w, int nsub, int cout, int cin, int wchp) {
   const int nt = cout / 16, nch = cin / 4;
-  const int wch = 49 * nt * 64, wchp = (wch + 255) / 256 * 256;
   std::vector<float> f((size_t)nsub * nch * wchp, 0.f);
   for (int b = 0; b < nsub; ++b)
     for (int ch = 0; ch < nch; ++ch)
@@ -543,10 +753,8 @@ std::vector<float> conv_fragments(const float* w, int nsub, int cout, int cin) {
 
 template <int LAYER, int SUB>
 hipError_t launch_conv(const ConvParams& cp, int grid, hipStream_t st) {
-  using C = CC<LAYER, SUB>;
-  constexpr int WCHP = (49 * C::NT * 64 + 255) / 256 * 256;
-  constexpr int PATCH = (4 * C::PR * C::PC + 3) / 4 * 4;
-  const size_t lds = (size_t)(2 * WCHP + kConvWaves * PATCH) * sizeof(float);
+  using GEO = ConvGeom<LAYER, SUB>;
+  const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
   static bool attr_set = false;  // one driver call per kernel per process, not per launch
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<LAYER, SUB>),
@@ -602,8 +810,8 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   std::vector<float> s1, t1, s2, t2;
   fold(w->conv1_b, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var, ns * 32, s1, t1);
   fold(w->conv2_b, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var, ns * 64, s2, t2);
-  auto f1 = conv_fragments(w->conv1_w, ns, 32, 8);
-  auto f2 = conv_fragments(w->conv2_w, ns, 64, 32);
+  auto f1 = conv_fragments(w->conv1_w, ns, 32, 8, ConvGeom<1, 2>::WBP);   // pitch does not depend on SUB
+  auto f2 = conv_fragments(w->conv2_w, ns, 64, 32, ConvGeom<2, 2>::WBP);
   auto w0t = transpose(w->mlp0_w, H, Fd), w3t = transpose(w->mlp3_w, H, H), hwt = transpose(w->head_w, ns * 192, H);
   MST_REQUIRE(E % 16 == 0, "mst_encoder_create: embed_dim must be a multiple of 16 (got %d)", E);
   std::vector<float> pfrag((size_t)(C / 4) * (E / 16) * 64);
@@ -691,7 +899,22 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     cp.tiles_c = e->sub == 2 ? (L.W1 + 7) / 8 : (L.W1 + 15) / 16;
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     const int g = std::min(grid, ns * cp.sets_per_band);
-    hipError_t err = e->sub == 2 ? launch_conv<1, 2>(cp, g, st) : launch_conv<1, 1>(cp, g, st);
+    hipError_t err;
+    if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
+      using C = CC<1, 2>;
+      constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 attribute failed: %s", hipGetErrorString(err));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv1_resident_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp);
+      err = hipGetLastError();
+    } else {
+      err = e->sub == 2 ? launch_conv<1, 2>(cp, g, st) : launch_conv<1, 1>(cp, g, st);
+    }
     if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 launch failed: %s", hipGetErrorString(err));
   }
   mark(2);
