@@ -9,7 +9,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmst.so")
+LIB_PATH = os.environ.get("MST_LIB", os.path.join(_HERE, "libmst.so"))  # MST_LIB: A/B-test another build
 CSRC = os.path.join(_HERE, "csrc")
 
 MST_OK = 0

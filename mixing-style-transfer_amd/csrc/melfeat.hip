@@ -17,13 +17,14 @@
 #include "common.h"
 #include "fft_wave.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
 namespace {
 
-constexpr int kWaves = 4;              // waves per workgroup
-constexpr int kFPW = 4;                // frames per wave per batch
+constexpr int kWaves = 8;              // waves per workgroup
+constexpr int kFPW = 2;                // frames per wave per batch
 constexpr int kTF = kWaves * kFPW;     // frames per workgroup batch (one LDS tile flush)
 constexpr int kTileStride = kTF + 1;   // +1: conflict-free transposed tile writes
 constexpr int kThreads = kWaves * 64;
@@ -47,8 +48,8 @@ enum : int {
   S_NFRAME = 66,  // [1] frames in this run
 };
 
-struct LaneBand {  // one mel band owned by a lane
-  int band, start, len, woff;
+struct LaneBand {  // one mel band owned by a lane: band id (-1 = none) and first bin of its support
+  int band, start;
 };
 
 struct KParams {
@@ -62,7 +63,8 @@ struct KParams {
   const float* melw;
   const LaneBand* lanebands;  // [NB][64]
   int B, T, F, M, hop;
-  int tw_count, nnz;
+  int tw_count, nnz;         // nnz = floats in the padded weight table melw[slot][i][lane]
+  int glen[4], goff[4];      // per band slot r: uniform gather length (max support over lanes) and table offset
   int frames_per_run, runs_per_clip, pstride;
   int vec_ok;  // 8-byte aligned float2 frame loads allowed
   int vec4_ok; // 16-byte aligned float4 stats loads allowed
@@ -80,7 +82,7 @@ __device__ __forceinline__ float2 shfl2(float2 a, int src) {
 template <int NFFT, int NB>
 __device__ __forceinline__ void frame_mel(const KParams& p, const float* __restrict__ xch, int frame, int lane,
                                           const float2* s_win, const float2* s_tw, const float2* s_post,
-                                          const float* s_melw, float2* scr, const LaneBand (&lb)[NB],
+                                          const float* s_melw, float2* scr, const int (&lb_start)[NB],
                                           float (&mel)[NB]) {
   constexpr int NC = NFFT / 2;
   constexpr int Q = NC / 64;
@@ -136,13 +138,15 @@ __device__ __forceinline__ void frame_mel(const KParams& p, const float* __restr
     const float ny = z0.x - z0.y;
     P[NC] = ny * ny;
   }
-  // sparse mel: each lane gathers its bands' contiguous supports
+  // sparse mel, branch-free: slot r of every lane walks glen[r] bins from its band's first bin; the weight table
+  // is zero beyond a band's true support, the bin index is clamped so that only finite values are touched
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
     float acc = 0.f;
-    const float* w = s_melw + lb[r].woff;
-    const float* pp = P + lb[r].start;
-    for (int i = 0; i < lb[r].len; ++i) acc = fmaf(w[i], pp[i], acc);
+    const float* w = s_melw + p.goff[r] + lane;
+    const int n = p.glen[r];
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) acc = fmaf(w[i * 64], P[min(lb_start[r] + i, NC)], acc);
     mel[r] = acc;
   }
 }
@@ -175,9 +179,12 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     for (int i = tid; i < NC; i += kThreads) s_post[i] = p.post[i];
     for (int i = tid; i < p.nnz; i += kThreads) s_melw[i] = p.melw[i];
   }
-  LaneBand lb[NB];
+  int lb_band[NB], lb_start[NB];
 #pragma unroll
-  for (int r = 0; r < NB; ++r) lb[r] = p.lanebands[r * 64 + lane];
+  for (int r = 0; r < NB; ++r) {
+    const LaneBand q = p.lanebands[r * 64 + lane];
+    lb_band[r] = q.band, lb_start[r] = q.start;
+  }
 
   auto chan = [&](int c) { return p.stem[c >> 1] + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T; };
   float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
@@ -308,14 +315,14 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
         for (int c = 0; c < 2; ++c) {
           float mel[NB];
           frame_mel<NFFT, NB>(p, chan(2 * s + c), frame, lane, s_win, s_tw, s_post, s_melw,
-                              scr, lb, mel);
+                              scr, lb_start, mel);
           float lsum = 0.f, msum = 0.f;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
-            const bool ok = lb[r].band >= 0;
+            const bool ok = lb_band[r] >= 0;
             const float lm = __log2f(mel[r] + 1e-10f) * kLn2;
             if (ok) {
-              s_tile[(c * M + lb[r].band) * kTileStride + wave * kFPW + fi] = lm;
+              s_tile[(c * M + lb_band[r]) * kTileStride + wave * kFPW + fi] = lm;
               lsum += lm;
               msum += mel[r];
             }
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
       if (fb + wave * kFPW + ff >= f_end) continue;
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
-        if (lb[r].band < 0) continue;
+        if (lb_band[r] < 0) continue;
 #pragma unroll
         for (int ss = 0; ss < 4; ++ss) {
           float other = -INFINITY;
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
           for (int j = 0; j < 4; ++j)
             if (j != ss) other = fmaxf(other, S[j][ff][r]);
           const float d = S[ss][ff][r] - other;
-          acc_mask[ss] += 1.0f / (1.0f + __expf(d));  // sigmoid((0 - d) / 1)
+          acc_mask[ss] += __frcp_rn(1.0f + __expf(d));  // sigmoid((0 - d) / 1)
         }
       }
     }
@@ -578,6 +585,7 @@ constexpr int tw_count_of() { return FftPlan<NFFT / 2>::TW; }
 struct mst_plan {
   int sr, n_fft, hop, n_mels, detailed_bins, feat_dim;
   int nc, nb, nnz, tw_count;
+  int glen[4], goff[4];
   int batches_per_run;
   float* d_window = nullptr;
   float2* d_tw = nullptr;
@@ -640,8 +648,7 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
   const int n_bins = n_fft / 2 + 1;
 
   // sparse mel table: per band contiguous support [start, start+len)
-  std::vector<int> start(n_mels, 0), len(n_mels, 0), woff(n_mels, 0);
-  std::vector<float> melw;
+  std::vector<int> start(n_mels, 0), len(n_mels, 0);
   for (int m = 0; m < n_mels; ++m) {
     int lo = -1, hi = -1;
     for (int k = 0; k < n_bins; ++k)
@@ -649,24 +656,33 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
         if (lo < 0) lo = k;
         hi = k;
       }
-    woff[m] = (int)melw.size();
-    if (lo >= 0) {
-      start[m] = lo, len[m] = hi - lo + 1;
-      for (int k = lo; k <= hi; ++k) melw.push_back(fb[(size_t)k * n_mels + m]);
+    if (lo >= 0) start[m] = lo, len[m] = hi - lo + 1;
+  }
+  // lane -> bands: slot r even: r/2*128 + lane ; r odd: (r/2)*128 + 127 - lane  (pairs a narrow low band with a
+  // wide high band).  Weights go into a zero-padded table melw[goff[r] + i*64 + lane], i < glen[r] = the longest
+  // support in slot r, so the gather loop has a uniform trip count and no divergence.
+  std::vector<LaneBand> lbs((size_t)p->nb * 64);
+  std::vector<float> melw;
+  for (int r = 0; r < 4; ++r) p->glen[r] = p->goff[r] = 0;
+  for (int r = 0; r < p->nb; ++r) {
+    int gl = 0;
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = (r / 2) * 128 + ((r & 1) ? 127 - lane : lane);
+      lbs[(size_t)r * 64 + lane] = (m < n_mels) ? LaneBand{m, start[m]} : LaneBand{-1, 0};
+      if (m < n_mels) gl = std::max(gl, len[m]);
+    }
+    p->glen[r] = gl;
+    p->goff[r] = (int)melw.size();
+    melw.resize(melw.size() + (size_t)gl * 64, 0.f);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = lbs[(size_t)r * 64 + lane].band;
+      if (m < 0) continue;
+      for (int i = 0; i < len[m]; ++i)
+        melw[(size_t)p->goff[r] + (size_t)i * 64 + lane] = fb[(size_t)(start[m] + i) * n_mels + m];
     }
   }
   p->nnz = (int)melw.size();
   if (melw.empty()) melw.push_back(0.f);
-  // lane -> bands: r even: r/2*128 + lane ; r odd: (r/2)*128 + 127 - lane  (pairs a narrow low band
-  // with a wide high band so the gather loop lengths are balanced across lanes)
-  std::vector<LaneBand> lbs((size_t)p->nb * 64);
-  for (int r = 0; r < p->nb; ++r)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int m = (r / 2) * 128 + ((r & 1) ? 127 - lane : lane);
-      LaneBand b{-1, 0, 0, 0};
-      if (m < n_mels) b = LaneBand{m, start[m], len[m], woff[m]};
-      lbs[(size_t)r * 64 + lane] = b;
-    }
   std::vector<float2> tw;
   for (auto pr : passes_of(p->nc)) add_pass_tw(tw, p->nc, pr.first, pr.second);
   p->tw_count = (int)tw.size();
@@ -730,6 +746,7 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   kp.window = p->d_window, kp.tw = p->d_tw, kp.post = p->d_post, kp.melw = p->d_melw, kp.lanebands = p->d_lanebands;
   kp.B = B, kp.T = T, kp.F = F, kp.M = p->n_mels, kp.hop = p->hop;
   kp.tw_count = p->tw_count, kp.nnz = p->nnz;
+  for (int r = 0; r < 4; ++r) kp.glen[r] = p->glen[r], kp.goff[r] = p->goff[r];
   kp.frames_per_run = p->batches_per_run * kTF;
   kp.runs_per_clip = runs_per_clip(p, F);
   kp.pstride = pstride_of(p);
