@@ -209,7 +209,8 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
   if (mode == 0) return;
   const int nitems = KIND == 0 ? p.NP : p.NX;
   if (item >= nitems) return;
-  float2 v[16];
+  float2 vv[1][16];
+  float2 (&v)[16] = vv[0];
   if (KIND == 0) {
     const float* h = p.ir + (size_t)b * p.L;
 #pragma unroll
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
                 : make_float2(0.f, 0.f);
     }
   }
-  FftPlan<kNfft>::run(v, lds.scr[wave], lds.tw, lane);
+  FftPlan<kNfft>::run<1>(vv, lds.scr[wave], lds.tw, lane);
   float2* dst = (KIND == 0 ? p.G + ((size_t)b * p.NP + item) * 1024 : p.X + ((size_t)b * p.NX + item) * 1024) + lane;
 #pragma unroll
   for (int r = 0; r < 16; ++r) dst[r * 64] = v[r];
@@ -262,13 +263,14 @@ __global__ __launch_bounds__(256) void rev_mac_ifft_kernel(const RevParams p) {
     }
   }
   // inverse FFT = conj(FFT(conj(Y))) / N; acc is in OUTPUT register order, the FFT wants INPUT register order
-  float2 v[16];
+  float2 vv[1][16];
+  float2 (&v)[16] = vv[0];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float2 y = acc[out_reg<kNfft>(in_q<kNfft>(r))];
     v[r] = make_float2(y.x, -y.y);
   }
-  FftPlan<kNfft>::run(v, lds.scr[wave], lds.tw, lane);
+  FftPlan<kNfft>::run<1>(vv, lds.scr[wave], lds.tw, lane);
   const float scale = 1.0f / (float)kNfft;
   const size_t co = (size_t)b * 8 * p.T;
   float pr[4];

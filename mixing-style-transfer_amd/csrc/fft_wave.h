@@ -58,27 +58,38 @@ struct Dft<8> {
 
 __device__ __forceinline__ int pad8(int e) { return e + (e >> 3); }
 
-// One Stockham pass of radix R with sub-transform length NS (product of earlier radices).
+// One Stockham pass of radix R with sub-transform length NS (product of earlier radices), applied to NF
+// independent FFTs at once (independent dependency chains for the scheduler; twiddles are loaded once).
 // Butterfly j = lane + 64*u takes x[j + t*NC/R], multiplies by W_{NS*R}^{(j % NS) t} and writes
 // y[(j / NS) * NS * R + j % NS + t * NS].  The LAST pass leaves natural order in registers:
-// v[u*R + t] = X[lane + 64*(u + t*NBF)].
-template <int NC, int R, int NS, bool FIRST, bool LAST>
-__device__ __forceinline__ void fft_pass(float2 (&v)[NC / 64], float2* scr, const float2* tw, int lane) {
+// v[f][u*R + t] = X_f[lane + 64*(u + t*NBF)].  FFT f uses the scratch at scr + f * (NC + NC/8).
+template <int NC, int R, int NS, bool FIRST, bool LAST, int NF>
+__device__ __forceinline__ void fft_pass(float2 (&v)[NF][NC / 64], float2* scr, const float2* tw, int lane) {
   constexpr int NBF = NC / R / 64;
   constexpr int STR = NC / R;
+  constexpr int SCR = NC + NC / 8;
   if constexpr (!FIRST) {
 #pragma unroll
     for (int u = 0; u < NBF; ++u)
 #pragma unroll
-      for (int t = 0; t < R; ++t) v[u * R + t] = scr[pad8(lane + 64 * u + t * STR)];
+      for (int t = 0; t < R; ++t) {
+        const int e = pad8(lane + 64 * u + t * STR);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f][u * R + t] = scr[f * SCR + e];
+      }
   }
 #pragma unroll
   for (int u = 0; u < NBF; ++u) {
     if constexpr (NS > 1) {
 #pragma unroll
-      for (int t = 1; t < R; ++t) v[u * R + t] = cmul(v[u * R + t], tw[(u * (R - 1) + (t - 1)) * 64 + lane]);
+      for (int t = 1; t < R; ++t) {
+        const float2 w = tw[(u * (R - 1) + (t - 1)) * 64 + lane];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f][u * R + t] = cmul(v[f][u * R + t], w);
+      }
     }
-    Dft<R>::run(&v[u * R]);
+#pragma unroll
+    for (int f = 0; f < NF; ++f) Dft<R>::run(&v[f][u * R]);
   }
   if constexpr (!LAST) {
 #pragma unroll
@@ -86,7 +97,11 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[NC / 64], float2* scr, cons
       const int j = lane + 64 * u;
       const int base = (j / NS) * NS * R + (j % NS);
 #pragma unroll
-      for (int t = 0; t < R; ++t) scr[pad8(base + t * NS)] = v[u * R + t];
+      for (int t = 0; t < R; ++t) {
+        const int e = pad8(base + t * NS);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) scr[f * SCR + e] = v[f][u * R + t];
+      }
     }
   }
 }
@@ -99,32 +114,35 @@ template <>
 struct FftPlan<256> {
   static constexpr int R0 = 4, RL = 4;
   static constexpr int TW = 3 * 3 * 64;
-  static __device__ __forceinline__ void run(float2 (&v)[4], float2* scr, const float2* tw, int lane) {
-    fft_pass<256, 4, 1, true, false>(v, scr, tw, lane);
-    fft_pass<256, 4, 4, false, false>(v, scr, tw, lane);
-    fft_pass<256, 4, 16, false, false>(v, scr, tw + 3 * 64, lane);
-    fft_pass<256, 4, 64, false, true>(v, scr, tw + 2 * 3 * 64, lane);
+  template <int NF>
+  static __device__ __forceinline__ void run(float2 (&v)[NF][4], float2* scr, const float2* tw, int lane) {
+    fft_pass<256, 4, 1, true, false, NF>(v, scr, tw, lane);
+    fft_pass<256, 4, 4, false, false, NF>(v, scr, tw, lane);
+    fft_pass<256, 4, 16, false, false, NF>(v, scr, tw + 3 * 64, lane);
+    fft_pass<256, 4, 64, false, true, NF>(v, scr, tw + 2 * 3 * 64, lane);
   }
 };
 template <>
 struct FftPlan<512> {
   static constexpr int R0 = 8, RL = 8;
   static constexpr int TW = 2 * 7 * 64;
-  static __device__ __forceinline__ void run(float2 (&v)[8], float2* scr, const float2* tw, int lane) {
-    fft_pass<512, 8, 1, true, false>(v, scr, tw, lane);
-    fft_pass<512, 8, 8, false, false>(v, scr, tw, lane);
-    fft_pass<512, 8, 64, false, true>(v, scr, tw + 7 * 64, lane);
+  template <int NF>
+  static __device__ __forceinline__ void run(float2 (&v)[NF][8], float2* scr, const float2* tw, int lane) {
+    fft_pass<512, 8, 1, true, false, NF>(v, scr, tw, lane);
+    fft_pass<512, 8, 8, false, false, NF>(v, scr, tw, lane);
+    fft_pass<512, 8, 64, false, true, NF>(v, scr, tw + 7 * 64, lane);
   }
 };
 template <>
 struct FftPlan<1024> {
   static constexpr int R0 = 8, RL = 4;
   static constexpr int TW = 2 * 7 * 64 + 4 * 3 * 64 + 4 * 3 * 64;
-  static __device__ __forceinline__ void run(float2 (&v)[16], float2* scr, const float2* tw, int lane) {
-    fft_pass<1024, 8, 1, true, false>(v, scr, tw, lane);
-    fft_pass<1024, 8, 8, false, false>(v, scr, tw, lane);
-    fft_pass<1024, 4, 64, false, false>(v, scr, tw + 2 * 7 * 64, lane);
-    fft_pass<1024, 4, 256, false, true>(v, scr, tw + 2 * 7 * 64 + 4 * 3 * 64, lane);
+  template <int NF>
+  static __device__ __forceinline__ void run(float2 (&v)[NF][16], float2* scr, const float2* tw, int lane) {
+    fft_pass<1024, 8, 1, true, false, NF>(v, scr, tw, lane);
+    fft_pass<1024, 8, 8, false, false, NF>(v, scr, tw, lane);
+    fft_pass<1024, 4, 64, false, false, NF>(v, scr, tw + 2 * 7 * 64, lane);
+    fft_pass<1024, 4, 256, false, true, NF>(v, scr, tw + 2 * 7 * 64 + 4 * 3 * 64, lane);
   }
 };
 

@@ -24,10 +24,11 @@
 namespace {
 
 constexpr int kWaves = 8;              // waves per workgroup
-constexpr int kFPW = 2;                // frames per wave per batch
+constexpr int kFPW = 2;                // frames per wave per batch = FFTs a wave runs side by side (ILP)
 constexpr int kTF = kWaves * kFPW;     // frames per workgroup batch (one LDS tile flush)
 constexpr int kTileStride = kTF + 1;   // +1: conflict-free transposed tile writes
 constexpr int kThreads = kWaves * 64;
+constexpr int nf_of(int n_fft) { return n_fft >= 2048 ? 1 : kFPW; }  // 2 side-by-side FFTs unless registers forbid
 constexpr int kNumScalars = 80;        // scalar slots per partial record (see enum below)
 
 // scalar slots of a partial record, after the 4*M per-band sums
@@ -78,29 +79,39 @@ __device__ __forceinline__ float2 shfl2(float2 a, int src) {
   return make_float2(__shfl(a.x, src, 64), __shfl(a.y, src, 64));
 }
 
-// mel power of one (channel, frame): returns this lane's NB band values.
-template <int NFFT, int NB>
-__device__ __forceinline__ void frame_mel(const KParams& p, const float* __restrict__ xch, int frame, int lane,
-                                          const float2* s_win, const float2* s_tw, const float2* s_post,
-                                          const float* s_melw, float2* scr, const int (&lb_start)[NB],
-                                          float (&mel)[NB]) {
+// mel power of NF frames of one channel, computed side by side (two independent FFT dependency chains per wave;
+// window, twiddles and mel weights are loaded once for both): returns this lane's NB band values per frame.
+template <int NFFT, int NB, int NF>
+__device__ __forceinline__ void frames_mel(const KParams& p, const float* __restrict__ xch, const int (&frame)[NF],
+                                           int lane, const float2* s_win, const float2* s_tw, const float2* s_post,
+                                           const float* s_melw, float2* scr, const int (&lb_start)[NB],
+                                           float (&mel)[NF][NB]) {
   constexpr int NC = NFFT / 2;
   constexpr int Q = NC / 64;
+  constexpr int SCR = NC + NC / 8;
   using Plan = FftPlan<NC>;
   constexpr int R0 = Plan::R0, RL = Plan::RL;
   constexpr int NBF0 = NC / R0 / 64, STR0 = NC / R0, NBFL = NC / RL / 64;
-  float2 v[Q];
-  const int s0 = frame * p.hop - NFFT / 2;
-  const bool interior = (s0 >= 0) && (s0 + NFFT <= p.T);
-  if (interior && p.vec_ok) {
-    const float2* x2 = reinterpret_cast<const float2*>(xch + s0);
+  float2 v[NF][Q];
+  int s0[NF];
+  bool interior = p.vec_ok != 0;
+#pragma unroll
+  for (int f = 0; f < NF; ++f) {
+    s0[f] = frame[f] * p.hop - NFFT / 2;
+    interior = interior && (s0[f] >= 0) && (s0[f] + NFFT <= p.T);
+  }
+  if (interior) {
 #pragma unroll
     for (int u = 0; u < NBF0; ++u)
 #pragma unroll
       for (int t = 0; t < R0; ++t) {
         const int n = lane + 64 * u + t * STR0;
-        const float2 x = x2[n], w = s_win[n];
-        v[u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
+        const float2 w = s_win[n];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const float2 x = reinterpret_cast<const float2*>(xch + s0[f])[n];
+          v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
+        }
       }
   } else {
 #pragma unroll
@@ -108,53 +119,68 @@ __device__ __forceinline__ void frame_mel(const KParams& p, const float* __restr
 #pragma unroll
       for (int t = 0; t < R0; ++t) {
         const int n = lane + 64 * u + t * STR0;
-        const int i0 = s0 + 2 * n;
-        const float xa = xch[reflect_idx(i0, p.T)], xb = xch[reflect_idx(i0 + 1, p.T)];
         const float2 w = s_win[n];
-        v[u * R0 + t] = make_float2(xa * w.x, xb * w.y);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          const int i0 = s0[f] + 2 * n;
+          v[f][u * R0 + t] = make_float2(xch[reflect_idx(i0, p.T)] * w.x, xch[reflect_idx(i0 + 1, p.T)] * w.y);
+        }
       }
   }
-  Plan::run(v, scr, s_tw, lane);
+  Plan::template run<NF>(v, scr, s_tw, lane);
 
   // real-FFT split: X[k] = E + W^k O with E,O from Z[k] and conj(Z[NC-k]); P = |X|^2
-  float* P = reinterpret_cast<float*>(scr);
   const int mirror = (64 - lane) & 63;
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     auto reg = [](int qq) { return (qq % NBFL) * RL + qq / NBFL; };
-    const float2 a = v[reg(q)];
-    const float2 bo = shfl2(v[reg(Q - 1 - q)], mirror);
-    const float2 bs = v[reg((Q - q) % Q)];
-    const float2 b = lane == 0 ? bs : bo;
     const float2 w = s_post[q * 64 + lane];
-    const float ex = 0.5f * (a.x + b.x), ey = 0.5f * (a.y - b.y);
-    const float ox = 0.5f * (a.y + b.y), oy = -0.5f * (a.x - b.x);
-    const float xr = ex + (w.x * ox - w.y * oy);
-    const float xi = ey + (w.x * oy + w.y * ox);
-    P[lane + 64 * q] = xr * xr + xi * xi;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const float2 a = v[f][reg(q)];
+      const float2 bo = shfl2(v[f][reg(Q - 1 - q)], mirror);
+      const float2 bs = v[f][reg((Q - q) % Q)];
+      const float2 b = lane == 0 ? bs : bo;
+      const float ex = 0.5f * (a.x + b.x), ey = 0.5f * (a.y - b.y);
+      const float ox = 0.5f * (a.y + b.y), oy = -0.5f * (a.x - b.x);
+      const float xr = ex + (w.x * ox - w.y * oy);
+      const float xi = ey + (w.x * oy + w.y * ox);
+      reinterpret_cast<float*>(scr + f * SCR)[lane + 64 * q] = xr * xr + xi * xi;
+    }
   }
   if (lane == 0) {
-    const float2 z0 = v[0];
-    const float ny = z0.x - z0.y;
-    P[NC] = ny * ny;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      const float ny = v[f][0].x - v[f][0].y;
+      reinterpret_cast<float*>(scr + f * SCR)[NC] = ny * ny;
+    }
   }
   // sparse mel, branch-free: slot r of every lane walks glen[r] bins from its band's first bin; the weight table
   // is zero beyond a band's true support, the bin index is clamped so that only finite values are touched
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    float acc = 0.f;
+    float acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = 0.f;
     const float* w = s_melw + p.goff[r] + lane;
     const int n = p.glen[r];
 #pragma unroll 4
-    for (int i = 0; i < n; ++i) acc = fmaf(w[i * 64], P[min(lb_start[r] + i, NC)], acc);
-    mel[r] = acc;
+    for (int i = 0; i < n; ++i) {
+      const float wi = w[i * 64];
+      const int k = min(lb_start[r] + i, NC);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) acc[f] = fmaf(wi, reinterpret_cast<const float*>(scr + f * SCR)[k], acc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) mel[f][r] = acc[f];
   }
 }
 
 template <int NFFT, int NB>
 __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
   constexpr int NC = NFFT / 2;
-  constexpr int SCR = NC + NC / 8;  // padded float2 per wave
+  constexpr int NF = nf_of(NFFT);            // FFTs a wave runs side by side
+  constexpr int SCR = NF * (NC + NC / 8);    // padded float2 per wave
   constexpr float kLn2 = 0.69314718055994530942f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2* s_win = reinterpret_cast<float2*>(smem);           // [NC] float2 = window pairs
@@ -306,35 +332,55 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
-#pragma unroll 1
-      for (int fi = 0; fi < kFPW; ++fi) {
-        const int frame = fb + wave * kFPW + fi;
-        if (frame >= f_end) continue;  // wave-uniform
-        float sm[NB];
+      int frame[kFPW];
+      bool fok[kFPW];
+#pragma unroll
+      for (int ff = 0; ff < kFPW; ++ff) {
+        const int fr = fb + wave * kFPW + ff;
+        fok[ff] = fr < f_end;
+        frame[ff] = fok[ff] ? fr : f_end - 1;  // past the run: recompute a valid frame, discard the result
+      }
+      if (fok[0]) {  // wave-uniform
+        float sm[kFPW][NB];
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
-          float mel[NB];
-          frame_mel<NFFT, NB>(p, chan(2 * s + c), frame, lane, s_win, s_tw, s_post, s_melw,
-                              scr, lb_start, mel);
-          float lsum = 0.f, msum = 0.f;
+          float mel[kFPW][NB];
+          if constexpr (NF == kFPW) {
+            frames_mel<NFFT, NB, kFPW>(p, chan(2 * s + c), frame, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, mel);
+          } else {
+#pragma unroll 1
+            for (int ff = 0; ff < kFPW; ++ff) {
+              const int one[1] = {frame[ff]};
+              float m1[1][NB];
+              frames_mel<NFFT, NB, 1>(p, chan(2 * s + c), one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
 #pragma unroll
-          for (int r = 0; r < NB; ++r) {
-            const bool ok = lb_band[r] >= 0;
-            const float lm = __log2f(mel[r] + 1e-10f) * kLn2;
-            if (ok) {
-              s_tile[(c * M + lb_band[r]) * kTileStride + wave * kFPW + fi] = lm;
-              lsum += lm;
-              msum += mel[r];
+              for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int f2 = 0; f2 < kFPW; ++f2) mel[f2][r] = (f2 == ff) ? m1[0][r] : mel[f2][r];
             }
-            const float lmz = ok ? lm : 0.f;
-#pragma unroll
-            for (int ss = 0; ss < 4; ++ss) acc_db[ss][r] += (s == ss) ? lmz : 0.f;
-            sm[r] = (c == 0) ? mel[r] : (sm[r] + mel[r]) * 0.5f;  // mel.mean(dim=0) of (2, M, F)
           }
 #pragma unroll
-          for (int ss = 0; ss < 4; ++ss) {
-            acc_log[ss] += (s == ss) ? lsum : 0.f;
-            acc_lin[ss] += (s == ss) ? msum : 0.f;
+          for (int ff = 0; ff < kFPW; ++ff) {
+            float lsum = 0.f, msum = 0.f;
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+              const bool ok = lb_band[r] >= 0 && fok[ff];
+              const float lm = __log2f(mel[ff][r] + 1e-10f) * kLn2;
+              if (ok) {
+                s_tile[(c * M + lb_band[r]) * kTileStride + wave * kFPW + ff] = lm;
+                lsum += lm;
+                msum += mel[ff][r];
+              }
+              const float lmz = ok ? lm : 0.f;
+#pragma unroll
+              for (int ss = 0; ss < 4; ++ss) acc_db[ss][r] += (s == ss) ? lmz : 0.f;
+              sm[ff][r] = (c == 0) ? mel[ff][r] : (sm[ff][r] + mel[ff][r]) * 0.5f;  // mel.mean(dim=0) of (2, M, F)
+            }
+#pragma unroll
+            for (int ss = 0; ss < 4; ++ss) {
+              acc_log[ss] += (s == ss) ? lsum : 0.f;
+              acc_lin[ss] += (s == ss) ? msum : 0.f;
+            }
           }
         }
 #pragma unroll
@@ -342,7 +388,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll
           for (int ff = 0; ff < kFPW; ++ff)
 #pragma unroll
-            for (int r = 0; r < NB; ++r) S[ss][ff][r] = (s == ss && fi == ff) ? sm[r] : S[ss][ff][r];
+            for (int r = 0; r < NB; ++r) S[ss][ff][r] = (s == ss) ? sm[ff][r] : S[ss][ff][r];
       }
       __syncthreads();
       if (p.logmel) {  // flush the stem's two channels: rows (c, band), kTF consecutive frames each
@@ -755,11 +801,12 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   kp.vec_ok = base16 && (T % 2 == 0) && (p->hop % 2 == 0) && (clip_stride % 2 == 0);
   kp.vec4_ok = base16 && (T % 4 == 0) && (p->hop % 4 == 0) && (clip_stride % 4 == 0);
   const int nc = p->nc;
-  size_t lds = (size_t)(nc + p->tw_count + nc + kWaves * (nc + nc / 8)) * sizeof(float2) +
+  const int nf = nf_of(p->n_fft);
+  size_t lds = (size_t)(nc + p->tw_count + nc + kWaves * nf * (nc + nc / 8)) * sizeof(float2) +
                (size_t)(((p->nnz + 3) & ~3) + 2 * p->n_mels * kTileStride) * sizeof(float);
   // the reduction buffers alias the FFT scratch: kWaves*4*NB*64 + kWaves*12 floats must fit
   const size_t red_need = (size_t)(kWaves * 4 * p->nb * 64 + kWaves * 12) * sizeof(float);
-  MST_REQUIRE(red_need <= (size_t)kWaves * (nc + nc / 8) * sizeof(float2), "internal: reduction buffer");
+  MST_REQUIRE(red_need <= (size_t)kWaves * nf * (nc + nc / 8) * sizeof(float2), "internal: reduction buffer");
   MST_REQUIRE(lds <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds);
   const int grid = B * kp.runs_per_clip;
   hipError_t e = hipErrorInvalidValue;
