@@ -10,3 +10,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/p
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/prof_${TAG}_sq -- python3 $R/bench.py $ARGS > $R/gpurun_out/prof_${TAG}_sq.log 2>&1
 ls -R $R/gpurun_out/prof_${TAG}_* | head -40
+# calibration of FETCH_SIZE / WRITE_SIZE for 4/8/16-byte-per-lane streams (1 GiB each)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_calibf -- $R/scripts/calib_fetch.bin > $R/gpurun_out/prof_${TAG}_calibf.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_calibw -- $R/scripts/calib_fetch.bin > $R/gpurun_out/prof_${TAG}_calibw.log 2>&1

@@ -19,7 +19,7 @@ for pass_ in ("fetch", "write", "sq"):
     for r in csv.DictReader(open(f[0])):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
-        if not any(x in k for x in ("melfeat", "conv_kernel", "attn_", "film_")):
+        if not any(x in k for x in ("melfeat", "conv", "attn_", "film_", "proj_", "read_k", "write_k")):
             continue
         for c, v in cs.items():
             out.setdefault("pmc", {}).setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
