@@ -149,31 +149,38 @@ __global__ __launch_bounds__(256) void aug_chain_kernel(const ChainParams p) {
 }
 
 // mean(stem^2) over (2, T) per stem  ->  redistribution weights E_s / (sum_s E_s + 1e-8)   (:410-416)
-__global__ __launch_bounds__(256) void aug_energy_kernel(const float* stems, const mst_aug_clip* dec, float* prop, int T) {
-  __shared__ double red[4][4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+constexpr int kEnergyBlocks = 32;  // partial sums per (clip, stem)
+
+__global__ __launch_bounds__(256) void aug_energy_partial_kernel(const float* stems, const mst_aug_clip* dec,
+                                                                 double* partial, int T) {
+  __shared__ double red[4];
+  const int b = blockIdx.y, s = blockIdx.x / kEnergyBlocks, blk = blockIdx.x % kEnergyBlocks;
   if (dec[b].reverb != 1) return;
-  double e[4];
-  for (int s = 0; s < 4; ++s) {
-    const float* x = stems + ((size_t)b * 8 + 2 * s) * T;
-    double a = 0.0;
-    for (int n = tid; n < 2 * T; n += 256) a += (double)x[n] * (double)x[n];
+  const int tid = threadIdx.x;
+  const float* x = stems + ((size_t)b * 8 + 2 * s) * T;
+  const int n_all = 2 * T, per = (n_all + kEnergyBlocks - 1) / kEnergyBlocks;
+  const int n0 = blk * per, n1 = min(n_all, n0 + per);
+  double a = 0.0;
+  for (int n = n0 + tid; n < n1; n += 256) a += (double)x[n] * (double)x[n];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    e[s] = a;
-  }
-  if (lane == 0)
-    for (int s = 0; s < 4; ++s) red[wave][s] = e[s];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = a;
   __syncthreads();
-  if (tid == 0) {
-    float E[4], tot = 0.f;
-    for (int s = 0; s < 4; ++s) {
-      E[s] = (float)(((red[0][s] + red[1][s]) + (red[2][s] + red[3][s])) / (2.0 * T));
-      tot += E[s];  // python sum([...]) : ((0 + E0) + E1) + E2) + E3
-    }
-    tot += 1e-8f;
-    for (int s = 0; s < 4; ++s) prop[b * 4 + s] = E[s] / tot;
+  if (tid == 0) partial[((size_t)b * 4 + s) * kEnergyBlocks + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void aug_energy_final_kernel(const mst_aug_clip* dec, const double* partial, float* prop, int T) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0 || dec[b].reverb != 1) return;
+  float E[4], tot = 0.f;
+  for (int s = 0; s < 4; ++s) {
+    double a = 0.0;
+    for (int k = 0; k < kEnergyBlocks; ++k) a += partial[((size_t)b * 4 + s) * kEnergyBlocks + k];
+    E[s] = (float)(a / (2.0 * T));
+    tot += E[s];  // python sum([...]) : (((0 + E0) + E1) + E2) + E3
   }
+  tot += 1e-8f;
+  for (int s = 0; s < 4; ++s) prop[b * 4 + s] = E[s] / tot;
 }
 
 struct RevParams {
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(256) void rev_mac_ifft_kernel(const RevParams p) {
 }
 
 struct AugLayout {
-  size_t dec, states, prop, G, X, total;
+  size_t dec, states, prop, epart, G, X, total;
   int nchunk, NP, NX, D, j0, nj;
 };
 
@@ -322,6 +329,7 @@ AugLayout aug_layout(int B, int T, int L) {
   a.dec = take((size_t)B * sizeof(mst_aug_clip));
   a.states = take((size_t)B * 8 * a.nchunk * 4 * sizeof(double));
   a.prop = take((size_t)B * 4 * sizeof(float));
+  a.epart = take((size_t)B * 4 * kEnergyBlocks * sizeof(double));
   a.G = take((size_t)B * a.NP * 1024 * sizeof(float2));
   a.X = take((size_t)B * a.NX * 1024 * sizeof(float2));
   a.total = o;
@@ -362,7 +370,9 @@ int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inou
   MST_HIP_CHECK(hipGetLastError());
   if (any_rev) {
     float* prop = reinterpret_cast<float*>(ws + L.prop);
-    hipLaunchKernelGGL(aug_energy_kernel, dim3(B), dim3(256), 0, st, stems_inout, ddec, prop, T);
+    double* epart = reinterpret_cast<double*>(ws + L.epart);
+    hipLaunchKernelGGL(aug_energy_partial_kernel, dim3(4 * kEnergyBlocks, B), dim3(256), 0, st, stems_inout, ddec, epart, T);
+    hipLaunchKernelGGL(aug_energy_final_kernel, dim3(B), dim3(64), 0, st, ddec, epart, prop, T);
     MST_HIP_CHECK(hipGetLastError());
     RevParams rp{stems_inout, ddec, reverb_ir, prop, reinterpret_cast<float2*>(ws + L.G),
                  reinterpret_cast<float2*>(ws + L.X), T, ir_len, L.NP, L.NX, L.D, L.j0, L.nj};

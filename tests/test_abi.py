@@ -64,3 +64,19 @@ def test_host_filterbank_matches_golden():
     for n_fft, n_mels in ((1024, 128), (1024, 256), (2048, 80)):
         assert np.array_equal(melscale_fbanks_htk(n_fft // 2 + 1, n_mels, 44100).numpy(), g[f"fb_{n_fft}_{n_mels}"])
         assert np.array_equal(hann_window(n_fft).numpy(), g[f"win_{n_fft}"])
+
+
+def test_closed_form_butterworth_matches_scipy():
+    """AudioAugmenter._butter4_low vs scipy.signal.butter(4, fc, 'low', output='sos'): same cascade to rounding."""
+    import numpy as np
+    from scipy.signal import butter, sosfilt
+    from mst_amd.mixing_utils import AudioAugmenter
+    aug = AudioAugmenter()
+    x = np.random.default_rng(0).standard_normal(20000)
+    for fc in (4000.0, 5123.456, 8000.0, 11999.9):
+        mine, ref = aug._butter4_low(fc), butter(4, fc, btype="low", fs=44100, output="sos")
+        tf = lambda sos: (np.convolve(sos[0, :3], sos[1, :3]), np.convolve(sos[0, 3:], sos[1, 3:]))
+        (b1, a1), (b2, a2) = tf(mine), tf(ref)
+        np.testing.assert_allclose(b1, b2, rtol=1e-12, atol=1e-16)
+        np.testing.assert_allclose(a1, a2, rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(sosfilt(mine, x), sosfilt(ref, x), rtol=0, atol=1e-12)
