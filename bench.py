@@ -84,11 +84,17 @@ def main():
     # host-side torch ops here are tiny (RNG draws, 22050-tap impulse responses): a 128-thread intra-op pool costs
     # milliseconds per op, so cap it at the box's per-GPU CPU share
     torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)) // max(1, world))))
+    if os.environ.get("MST_BENCH_ONE_GPU"):   # rehearsal of the N>1 control flow on a 1-GPU box (all ranks on cuda:0)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MST_BENCH_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only for the rehearsal
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from mst_amd.loss import InfoNCELoss
