@@ -121,3 +121,26 @@ def test_unsupported_geometry_fails_loudly():
     m = MixingStyleEncoder(n_mels=128, split_size=40, overlap=20, feature_dim=64).cuda().eval()  # pool height 4
     with pytest.raises(_lib.MstError):
         m.hip_encoder()
+
+
+def test_config5_geometry_30s_256_mels():
+    """BASELINE configs[4] shapes: 30 s clips (F = 5168), n_mels = 256 -> 24 sub-bands, attention input (B, 3072, 258)."""
+    cfg = dict(sample_rate=44100, n_fft=1024, hop_length=256, n_mels=256, split_size=20, overlap=10, embed_dim=768)
+    model, sd = build_model(cfg)
+    assert model.audio_encoder.n_subbands == 24
+    T = 30 * 44100
+    x = cases.synth_clip(2, T)[None]
+    from mst_amd.mixing_utils import MixingFeatureExtractor
+    from oracle import features as ofeat
+    stems = omel.tensor_to_stems_dict(x.cuda())
+    feats, lm = MixingFeatureExtractor(44100, 1024, 256, 256).features_and_logmel(stems)
+    assert tuple(lm.shape) == (1, 8, 256, 5168)
+    rf, rmel = ofeat.extract_all_features(x, 44100, 1024, 256, 256, return_mel=True)
+    np.testing.assert_allclose(feats.cpu().numpy(), rf.numpy(), rtol=1e-4, atol=2e-4)
+    from test_melfeat_gpu import check_logmel
+    check_logmel(lm.cpu(), torch.log(rmel + 1e-10), x=x, cfg=(44100, 1024, 256, 256))
+    with torch.no_grad():
+        emb, taps = model.hip_encoder().forward(lm, feats, taps=True)
+    assert tuple(taps["pool_in"].shape) == (1, 3072, 258)
+    ref = oenc.encoder_from_logmel(sd, lm.cpu(), feats.cpu(), 20, 10)
+    close(emb.cpu(), ref)
