@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--encoder", choices=["auto", "hip", "torch"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
+                    help="conv1 arithmetic: exact fp32 MFMA (default) or opt-in 3-term split-precision f16 MFMA")
     ap.add_argument("--aug", action="store_true", help="also run the augmentation chain on the negative clip of every triplet inside the timed step (BASELINE configs[3] without SCNet)")
     return ap.parse_args()
 
@@ -115,6 +117,7 @@ def main():
             b[i * 192:i * 192 + 32] += 1.0
             b[i * 192 + 64:i * 192 + 128] += 1.0
     model = model.to(dev).eval()
+    model.conv1_precision = a.precision
     fe = MixingFeatureExtractor(sr, n_fft, hop, n_mels)
     crit = InfoNCELoss(0.1, gather=world > 1)
     augm = AudioAugmenter(sr, 9.0, 0.5)
@@ -223,7 +226,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if a.precision == "fp32" else "f32 (conv1: f16x3 split-precision MFMA, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": ("configs[2]" if backend == "hip" else "configs[1]") +
                        f": synthetic {a.seconds:.0f} s stereo 4-stem clips, {a.triplets} triplets = {B} clips per GPU, "
@@ -231,7 +234,7 @@ def main():
                        ("HIP (fp32 MFMA)" if backend == "hip" else "PyTorch-ROCm") +
                        ", InfoNCE on all-gathered embeddings" + (", HIP augmentation chain on the negatives" if a.aug else ""),
                        "clips_per_gpu": B, "clip_samples": T, "n_fft": n_fft, "hop": hop, "n_mels": n_mels,
-                       "encoder_backend": backend, "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
+                       "encoder_backend": backend, "conv1_precision": a.precision, "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:

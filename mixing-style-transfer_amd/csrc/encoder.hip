@@ -525,6 +525,184 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 }
 
 // ------------------------------------------------------------------------------------------
+// OPT-IN conv1 on the f16 matrix cores with 3-term split precision (mst_encoder_set_precision(enc, 1)).
+// x = xh + xl, w = wh + wl (f16 each, 22 significant bits together; weights pre-scaled by 2^10 so that wl stays a
+// normal f16), x*w ~= xh*wh + xh*wl + xl*wh exactly representable products, fp32 accumulation in the MFMA
+// (v_mfma_f32_16x16x32_f16).  Per-product relative error ~2^-22 (fp32: 2^-24); parity-tested at the same 1e-4 bar.
+// Same tile / epilogue structure as conv1_resident_kernel; a k-step is 4 taps x 8 input channels (13 steps, the
+// last 3 tap slots carry zero weights); the patch is stored channel-minor ([row][col][8 ch] f16, hi and lo) so an
+// A fragment is one ds_read_b128.  The default path stays the exact-fp32 kernel above.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+constexpr float kF16Scale = 1024.0f;  // weight pre-scale (folded back in the epilogue)
+constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
+
+template <int SUB>
+__global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16) {
+  using C = CC<1, SUB>;
+  constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
+  static_assert(C::RL == 64, "one loader row per instruction");
+  constexpr int WVEC = kF16Steps * NT * 2 * 64;      // h16x8 vectors of one band's weights: [step][nt][hi/lo][lane]
+  constexpr int PVEC = PR * PC;                      // positions per patch (one h16x8 = 8 channels each)
+  constexpr int NPF = 8 * PR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  h16x8* wres = reinterpret_cast<h16x8*>(smem);                  // [WVEC]
+  h16x8* phi = wres + WVEC + wave * 2 * PVEC;                     // wave-private patch, hi part
+  h16x8* plo = phi + PVEC;                                        //                     lo part
+
+  const int G = gridDim.x;
+  const int wg = mst::xcd_remap(blockIdx.x, G);
+  const int total_sets = p.nsub * p.sets_per_band;
+  const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
+  const int tpb = p.tiles_r * p.tiles_c;
+
+  auto decode = [&](int s) __attribute__((always_inline)) {
+    Tile t;
+    t.band = min(s / p.sets_per_band, p.nsub - 1);
+    const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
+    t.valid = (s < s_end) && idx < p.B * tpb;
+    t.clip = t.valid ? idx / tpb : 0;
+    const int ti = t.valid ? idx - t.clip * tpb : 0;
+    t.tc = ti / p.tiles_r;
+    t.tr = ti - t.tc * p.tiles_r;
+    return t;
+  };
+
+  const int kq = lane >> 4, ai = lane & 15, ag = ai >> 2, areg = ai & 3;
+  int abase[MT];   // position index of A row (lane & 15) of M-tile t inside the patch
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int e = 4 * t + areg, wv = e / C::WIN, pos = e % C::WIN;
+    abase[t] = (pos / 5) * PC + 5 * (C::WPG * ag + wv) + pos % 5;
+  }
+  int toff[kF16Steps];  // patch offset of this lane group's tap in every k-step (tap = 4 s + kq; padded slots reuse tap 48)
+#pragma unroll
+  for (int st = 0; st < kF16Steps; ++st) {
+    const int tap = min(4 * st + kq, 48);
+    toff[st] = (tap / 7) * PC + tap % 7;
+  }
+
+  float pf[NPF];
+  unsigned long long rowmask = 0;
+  bool col_ok = false;
+  int coff = 0, nrow0 = 0, nvalid = 0;
+  const float* nsrc = p.in;
+  auto prefetch_setup = [&](const Tile& t) __attribute__((always_inline)) {
+    nrow0 = C::TROWS * t.tr - 3;
+    const int cin = C::TCOLS * t.tc - 3 + lane;
+    nvalid = t.valid;
+    nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
+    col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
+    coff = min(max(cin, 0), p.in_cols - 1);
+    rowmask = 0;
+  };
+  auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
+    if (i < NPF) {
+      const int cc = i / PR, r = i % PR;
+      const int rin = nrow0 + r;
+      const int rc = min(max(rin, 0), p.in_rows - 1);
+      if (nvalid && rin == rc) rowmask |= 1ull << i;
+      pf[i] = (nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[coff];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  int cur_band = -1;
+  Tile cur{}, nxt = decode(s_begin);
+  prefetch_setup(nxt);
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+
+  for (int s = s_begin; s < s_end; ++s) {
+    cur = nxt;
+    if (cur.band != cur_band) {
+      __syncthreads();
+      const h16x8* src = wfrag16 + (size_t)cur.band * WVEC;
+      for (int k = tid; k < WVEC; k += kConvThreads) wres[k] = src[k];
+      __syncthreads();
+      cur_band = cur.band;
+    }
+    // stage the prefetched fp32 patch as f16 hi / lo, channel-minor: one 16-byte vector per position
+    if (lane < PC) {
+#pragma unroll
+      for (int r = 0; r < PR; ++r) {
+        h16x8 vh, vl;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const int i = cc * PR + r;
+          const float x = (((rowmask >> i) & 1ull) && col_ok) ? pf[i] : 0.f;
+          const _Float16 h = (_Float16)x;
+          vh[cc] = h;
+          vl[cc] = (_Float16)(x - (float)h);
+        }
+        phi[r * PC + lane] = vh;
+        plo[r * PC + lane] = vl;
+      }
+    }
+    nxt = decode(s + 1);
+    prefetch_setup(nxt);
+    if (!cur.valid) {
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+      continue;
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < kF16Steps; ++st) {
+      h16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
+        bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        ah[t] = phi[abase[t] + toff[st]];
+        al[t] = plo[abase[t] + toff[st]];
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) prefetch_piece(st * 5 + k);   // 64 row loads of the next tile over 13 steps
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);  // small terms first
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
+        }
+    }
+    {
+      const int j = lane & 15, g = lane >> 4;
+      const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
+      float* orow = p.out + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT * p.out_rows * p.out_cols +
+                    (size_t)cur.tr * p.out_cols;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = n * 16 + j;
+        float2 ac = aff[ch];
+        ac.x *= (1.0f / kF16Scale);  // undo the weight pre-scale
+#pragma unroll
+        for (int wv = 0; wv < C::WPG; ++wv) {
+          float m = 0.f;
+#pragma unroll
+          for (int pos = 0; pos < C::WIN; ++pos) {
+            const int e = wv * C::WIN + pos;
+            m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
+          }
+          const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
+          if (pc < p.out_cols) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attention scores: s[b][t] = w2 . tanh(W1 x[b,:,t] + b1) + b2      (model.py:198-200)
 // fp32-MFMA GEMM.  One workgroup = 16 frames; its 4 waves split the 256 hidden units (4 N-tiles each) and
 // combine their partial dot products through LDS.  W1 is pre-swizzled into B-fragment order.
@@ -697,6 +875,8 @@ struct mst_encoder {
   float *att0frag = nullptr, *att0_b = nullptr, *att2_w = nullptr, *projfrag = nullptr, *proj_b = nullptr;
   float att2_b = 0.f;
   int num_cus = 256;
+  void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
+  int conv1_f16x3 = 0;
 };
 
 namespace {
@@ -825,7 +1005,26 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
       for (int lane = 0; lane < 64; ++lane)
         af[((size_t)s * (A / 16) + n) * 64 + lane] = w->att0_w[(size_t)(n * 16 + (lane & 15)) * C + 4 * s + (lane >> 4)];
   e->att2_b = w->att2_b[0];
+  // conv1 weights, f16 hi/lo split of (2^10 * w): [band][step][nt][hi/lo][lane][8 channels]
+  std::vector<_Float16> f16((size_t)ns * kF16Steps * 2 * 2 * 64 * 8);
+  for (int b = 0; b < ns; ++b)
+    for (int st = 0; st < kF16Steps; ++st)
+      for (int n = 0; n < 2; ++n)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int tap = 4 * st + (lane >> 4), co = n * 16 + (lane & 15);
+            const float wv = tap < 49 ? kF16Scale * w->conv1_w[(((size_t)b * 32 + co) * 8 + j) * 49 + tap] : 0.f;
+            const _Float16 h = (_Float16)wv;
+            const size_t base = ((((size_t)b * kF16Steps + st) * 2 + n) * 2) * 64 * 8;
+            f16[base + (size_t)lane * 8 + j] = h;
+            f16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(wv - (float)h);
+          }
   int rc = 0;
+  {
+    _Float16* d16 = nullptr;
+    rc = mst::upload(&d16, f16.data(), f16.size());
+    e->w1frag16 = d16;
+  }
 #define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
 #define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
   UP(w1frag, f1); UP(w2frag, f2); UP(s1, s1); UP(t1, t1); UP(s2, s2); UP(t2, t2);
@@ -847,7 +1046,16 @@ void mst_encoder_destroy(mst_encoder* e) {
   float* ptrs[] = {e->w1frag, e->w2frag, e->s1, e->t1, e->s2, e->t2, e->w0t, e->b0, e->w3t, e->b3, e->hwt,
                    e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b};
   for (float* q : ptrs) (void)hipFree(q);
+  (void)hipFree(e->w1frag16);
   delete e;
+}
+
+int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
+  MST_REQUIRE(e, "mst_encoder_set_precision: NULL encoder");
+  MST_REQUIRE(conv1_f16x3 == 0 || (conv1_f16x3 == 1 && e->sub == 2),
+              "mst_encoder_set_precision: f16x3 conv1 needs the default 20-mel sub-bands (pool height 2)");
+  e->conv1_f16x3 = conv1_f16x3;
+  return MST_OK;
 }
 
 size_t mst_encoder_workspace_bytes(const mst_encoder* e, int B, int frames) {
@@ -900,7 +1108,20 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     const int g = std::min(grid, ns * cp.sets_per_band);
     hipError_t err;
-    if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
+    if (e->sub == 2 && e->conv1_f16x3) {
+      using C = CC<1, 2>;
+      constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
+      static bool attr16 = false;
+      if (!attr16) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
+        attr16 = true;
+      }
+      hipLaunchKernelGGL((conv1_f16x3_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp,
+                         reinterpret_cast<const h16x8*>(e->w1frag16));
+      err = hipGetLastError();
+    } else if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
       static bool attr_set = false;

@@ -174,7 +174,7 @@ class MixingFeatureEncoder(nn.Module):
 class HipEncoder:
     """Owns an `mst_encoder` handle built from a module's current parameters (eval-mode forward in HIP)."""
 
-    def __init__(self, model: "MixingStyleEncoder"):
+    def __init__(self, model: "MixingStyleEncoder", conv1_precision="fp32"):
         ae, fe = model.audio_encoder, model.film_encoder
         cpu = lambda t: t.detach().float().cpu().contiguous()
         cat = lambda name: cpu(torch.stack([getattr(getattr(c, name.split(".")[0]), name.split(".")[1])
@@ -197,6 +197,9 @@ class HipEncoder:
         h = C.c_void_p()
         _lib.check(_lib.lib().mst_encoder_create(C.byref(h), C.byref(self.cfg), C.byref(w)), "mst_encoder_create")
         self._h = h
+        if conv1_precision not in ("fp32", "f16x3"):
+            raise ValueError("conv1_precision must be 'fp32' (exact, default) or 'f16x3' (split-precision f16 MFMA)")
+        _lib.check(_lib.lib().mst_encoder_set_precision(h, int(conv1_precision == "f16x3")), "mst_encoder_set_precision")
         self._ws = None
         self.embed_dim = ae.attention_pooling.output_dim
         self.n_sub, self.split, self.freq_dim = ae.n_subbands, ae.split_size, ae.freq_dim
@@ -248,6 +251,7 @@ class MixingStyleEncoder(nn.Module):
                                               embed_dim)
         self.film_encoder = MixingFeatureEncoder(feature_dim, self.audio_encoder.n_subbands)
         self.encoder_backend = encoder_backend
+        self.conv1_precision = "fp32"   # "f16x3": opt-in split-precision f16 MFMA for conv1 (see include/mst.h)
         self._hip = None
         self._hip_version = None
 
@@ -255,9 +259,9 @@ class MixingStyleEncoder(nn.Module):
         return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
 
     def hip_encoder(self) -> HipEncoder:
-        v = self._params_version()
+        v = self._params_version() + (self.conv1_precision,)
         if self._hip is None or v != self._hip_version:  # weights changed (optimizer step / load_state_dict)
-            self._hip, self._hip_version = HipEncoder(self), v
+            self._hip, self._hip_version = HipEncoder(self, self.conv1_precision), v
         return self._hip
 
     def _needs_autograd(self, mixing_features):

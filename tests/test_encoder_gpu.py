@@ -144,3 +144,31 @@ def test_config5_geometry_30s_256_mels():
     assert tuple(taps["pool_in"].shape) == (1, 3072, 258)
     ref = oenc.encoder_from_logmel(sd, lm.cpu(), feats.cpu(), 20, 10)
     close(emb.cpu(), ref)
+
+
+@pytest.mark.parametrize("tag,T", [("default", 441000), ("default_short", 66150)])
+def test_conv1_f16x3_split_precision_meets_the_fp32_bar(tag, T):
+    """Opt-in conv1 on the f16 matrix cores (3-term split): same goldens, same 1e-4 tolerance as the exact path;
+    also reports how far it is from the exact-fp32 kernel."""
+    g = np.load(os.path.join(G, "encoder.npz"))
+    cfg = cases.CFG_DEFAULT
+    model, sd = build_model(cfg)
+    x = torch.stack([cases.synth_clip(c, T) for c in (0, 1)], 0)
+    feats = torch.from_numpy(g[f"{tag}.features"]).cuda()
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        e32, t32 = model.hip_encoder().forward(lm, feats, taps=True)
+        model.conv1_precision = "f16x3"
+        e16, t16 = model.hip_encoder().forward(lm, feats, taps=True)
+        model.conv1_precision = "fp32"
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    p1 = t16["pool1"].cpu()
+    for i in (0, ns // 2, ns - 1):
+        idx = torch.from_numpy(g[f"{tag}.pool1_{i}_idx"])
+        close(p1[:, i].flatten()[idx], g[f"{tag}.pool1_{i}_samples"])
+    close(t16["pool_in"].cpu().flatten()[torch.from_numpy(g[f"{tag}.pool_in_idx"])], g[f"{tag}.pool_in_samples"])
+    close(e16.cpu(), g[f"{tag}.embedding"])
+    d_pool = (t16["pool1"] - t32["pool1"]).abs().max().item() / t32["pool1"].abs().max().item()
+    d_emb = (e16 - e32).abs().max().item() / e32.abs().max().item()
+    print(f"f16x3 vs exact fp32: pool1 {d_pool:.2e}, embedding {d_emb:.2e} (relative to max)")
+    assert d_pool < 2e-6 and d_emb < 1e-5
