@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--encoder", choices=["auto", "hip", "torch"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "f16x3"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "f16x3", "f16x3-all"], default="fp32",
                     help="conv1 arithmetic: exact fp32 MFMA (default) or opt-in 3-term split-precision f16 MFMA")
     ap.add_argument("--aug", action="store_true", help="also run the augmentation chain on the negative clip of every triplet inside the timed step (BASELINE configs[3] without SCNet)")
     return ap.parse_args()
@@ -226,7 +226,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if a.precision == "fp32" else "f32 (conv1: f16x3 split-precision MFMA, fp32 accumulate)",
+            "dtype": "f32" if a.precision == "fp32" else f"f32 ({a.precision}: convs on split-precision f16 MFMA, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": ("configs[2]" if backend == "hip" else "configs[1]") +
                        f": synthetic {a.seconds:.0f} s stereo 4-stem clips, {a.triplets} triplets = {B} clips per GPU, "

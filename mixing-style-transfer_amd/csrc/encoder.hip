@@ -538,7 +538,8 @@ constexpr float kF16Scale = 1024.0f;  // weight pre-scale (folded back in the ep
 constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
 
 template <int SUB>
-__global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16) {
+__global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16,
+                                                                  _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo) {
   using C = CC<1, SUB>;
   constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
   static_assert(C::RL == 64, "one loader row per instruction");
@@ -695,8 +696,156 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
             m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
           }
           const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
-          if (pc < p.out_cols) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
+          if (pc < p.out_cols) {
+            if (p.out) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
+            if (out_hi) {  // conv2's split-precision input: [clip][band][row][col][32 ch] f16, hi and lo
+              const size_t o = ((((size_t)cur.clip * p.nsub + cur.band) * p.out_rows + cur.tr) * p.out_cols + pc) * 32 + ch;
+              const _Float16 h = (_Float16)m;
+              out_hi[o] = h;
+              out_lo[o] = (_Float16)(m - (float)h);
+            }
+          }
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// OPT-IN conv2 on the f16 matrix cores, 3-term split precision (mst_encoder_set_precision(enc, 2)).
+// Input: conv1's pooled activations as f16 hi/lo, channel-minor.  A k-step is 4 taps x 8 input channels; the 32
+// input channels are processed in 4 chunks of 8 (13 k-steps each; the chunk's 104 KB of hi/lo weight fragments are
+// shared by the 8 waves, every wave has a private 14x14-position patch).  Activations above the f16 range (65504)
+// would saturate: the Python wrapper checks max(pool1) once before enabling this mode.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ in_hi,
+                                                                  const h16x8* __restrict__ in_lo,
+                                                                  const h16x8* __restrict__ wfrag16) {
+  constexpr int MT = 4, NT = 4, NCH = 4, PR = 14, PC = 14, NPOS = PR * PC;
+  constexpr int WV = kF16Steps * NT * 2 * 64;         // h16x8 vectors per weight chunk (6656 = 13 per thread)
+  constexpr int NWF = WV / kConvThreads;
+  constexpr int NPF = (NPOS + 63) / 64;               // position vectors per lane (hi and lo each)
+  static_assert(WV % kConvThreads == 0, "weight chunk must split evenly");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  h16x8* wres = reinterpret_cast<h16x8*>(smem);       // [WV]
+  h16x8* phi = wres + WV + wave * 2 * NPOS;
+  h16x8* plo = phi + NPOS;
+
+  const int G = gridDim.x;
+  const int wg = mst::xcd_remap(blockIdx.x, G);
+  const int total_sets = p.nsub * p.sets_per_band;
+  const int my_sets = wg < total_sets ? (total_sets - wg + G - 1) / G : 0;
+  const int nq = my_sets * NCH;
+  const int tpb = p.tiles_r * p.tiles_c;
+  auto decode = [&](int q) __attribute__((always_inline)) {
+    const int s = wg + (q / NCH) * G;
+    Tile t;
+    t.band = min(s / p.sets_per_band, p.nsub - 1);
+    const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
+    t.valid = (q < nq) && idx < p.B * tpb;
+    t.clip = t.valid ? idx / tpb : 0;
+    const int ti = t.valid ? idx - t.clip * tpb : 0;
+    t.tc = ti / p.tiles_r;
+    t.tr = ti - t.tc * p.tiles_r;
+    return t;
+  };
+  const int kq = lane >> 4, ai = lane & 15, ag = ai >> 2, areg = ai & 3;
+  int abase[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) abase[t] = (4 * (ag >> 1) + t) * PC + 4 * (ag & 1) + areg;
+  int toff[kF16Steps];
+#pragma unroll
+  for (int st = 0; st < kF16Steps; ++st) {
+    const int tap = min(4 * st + kq, 48);
+    toff[st] = (tap / 7) * PC + tap % 7;
+  }
+
+  h16x8 wreg[NWF], ph[NPF], pl[NPF];
+  auto prefetch = [&](int q, const Tile& t) __attribute__((always_inline)) {
+    const int chunk = q % NCH;
+    const h16x8* wsrc = wfrag16 + ((size_t)t.band * NCH + chunk) * WV;
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) wreg[i] = wsrc[tid + kConvThreads * i];
+    const int row0 = 8 * t.tr - 3, col0 = 8 * t.tc - 3;
+    const size_t plane = ((size_t)t.clip * p.nsub + t.band) * p.in_rows;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = lane + 64 * i;
+      const int r = e / PC, c = e - r * PC;
+      const int rin = row0 + r, cin = col0 + c;
+      const int rc = min(max(rin, 0), p.in_rows - 1), cl = min(max(cin, 0), p.in_cols - 1);
+      const bool ok = t.valid && e < NPOS && rin == rc && cin == cl;
+      const size_t v = ((plane + rc) * p.in_cols + cl) * 4 + chunk;
+      const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      const h16x8 a = in_hi[v], b = in_lo[v];
+      ph[i] = ok ? a : z;
+      pl[i] = ok ? b : z;
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  Tile cur{}, nxt = decode(0);
+  if (nq > 0) prefetch(0, nxt);
+  for (int q = 0; q < nq; ++q) {
+    __syncthreads();  // every wave is done with the previous chunk's weights
+#pragma unroll
+    for (int i = 0; i < NWF; ++i) wres[tid + kConvThreads * i] = wreg[i];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int e = lane + 64 * i;
+      if (e < NPOS) phi[e] = ph[i], plo[e] = pl[i];
+    }
+    __syncthreads();
+    cur = nxt;
+    nxt = decode(q + 1);
+    prefetch(q + 1, nxt);   // lands while this chunk is on the MFMAs; past the end it re-reads valid memory
+    const int chunk = q % NCH;
+    if (chunk == 0) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int st = 0; st < kF16Steps; ++st) {
+      h16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
+        bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        ah[t] = phi[abase[t] + toff[st]];
+        al[t] = plo[abase[t] + toff[st]];
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
+        }
+    }
+    if (chunk == NCH - 1 && cur.valid) {
+      const int j = lane & 15, g = lane >> 4;
+      const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * 64;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = n * 16 + j;
+        float2 ac = aff[ch];
+        ac.x *= (1.0f / kF16Scale);
+        float m = 0.f;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaf(acc[t][n][r], ac.x, ac.y));
+        const int pr = 2 * cur.tr + (g >> 1), pc = 2 * cur.tc + (g & 1);
+        if (pr < p.out_rows && pc < p.out_cols)
+          p.out[(((size_t)cur.clip * p.nsub + cur.band) * 64 + ch) * p.out_rows * p.out_cols + (size_t)pr * p.out_cols + pc] = m;
       }
     }
   }
@@ -876,13 +1025,14 @@ struct mst_encoder {
   float att2_b = 0.f;
   int num_cus = 256;
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
-  int conv1_f16x3 = 0;
+  void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
+  int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3
 };
 
 namespace {
 
 struct WsLayout {
-  size_t film, aff1, aff2, pool1, pool_in, scores, pooled, total;
+  size_t film, aff1, aff2, pool1, pool1_h16, pool1_l16, pool_in, scores, pooled, total;
   int W1, W2;
 };
 
@@ -901,6 +1051,8 @@ WsLayout ws_layout(const mst_encoder* e, int B, int frames) {
   L.aff1 = take((size_t)B * ns * 32 * 8);
   L.aff2 = take((size_t)B * ns * 64 * 8);
   L.pool1 = take((size_t)B * ns * 32 * e->H1 * L.W1 * 4);
+  L.pool1_h16 = take(e->conv1_f16x3 == 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
+  L.pool1_l16 = take(e->conv1_f16x3 == 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
   L.pool_in = take((size_t)B * e->C * L.W2 * 4);
   L.scores = take((size_t)B * L.W2 * 4);
   L.pooled = take((size_t)B * e->C * 4);
@@ -1019,11 +1171,26 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
             f16[base + (size_t)lane * 8 + j] = h;
             f16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(wv - (float)h);
           }
+  std::vector<_Float16> g16((size_t)ns * 4 * kF16Steps * 4 * 2 * 64 * 8);
+  for (int b = 0; b < ns; ++b)
+    for (int ck = 0; ck < 4; ++ck)
+      for (int st = 0; st < kF16Steps; ++st)
+        for (int n = 0; n < 4; ++n)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int tap = 4 * st + (lane >> 4), co = n * 16 + (lane & 15), ci = ck * 8 + j;
+              const float wv = tap < 49 ? kF16Scale * w->conv2_w[(((size_t)b * 64 + co) * 32 + ci) * 49 + tap] : 0.f;
+              const _Float16 h = (_Float16)wv;
+              const size_t base = (((((size_t)b * 4 + ck) * kF16Steps + st) * 4 + n) * 2) * 64 * 8;
+              g16[base + (size_t)lane * 8 + j] = h;
+              g16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(wv - (float)h);
+            }
   int rc = 0;
   {
-    _Float16* d16 = nullptr;
+    _Float16 *d16 = nullptr, *e16 = nullptr;
     rc = mst::upload(&d16, f16.data(), f16.size());
-    e->w1frag16 = d16;
+    if (!rc) rc = mst::upload(&e16, g16.data(), g16.size());
+    e->w1frag16 = d16, e->w2frag16 = e16;
   }
 #define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
 #define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
@@ -1047,13 +1214,14 @@ void mst_encoder_destroy(mst_encoder* e) {
                    e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b};
   for (float* q : ptrs) (void)hipFree(q);
   (void)hipFree(e->w1frag16);
+  (void)hipFree(e->w2frag16);
   delete e;
 }
 
 int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
   MST_REQUIRE(e, "mst_encoder_set_precision: NULL encoder");
-  MST_REQUIRE(conv1_f16x3 == 0 || (conv1_f16x3 == 1 && e->sub == 2),
-              "mst_encoder_set_precision: f16x3 conv1 needs the default 20-mel sub-bands (pool height 2)");
+  MST_REQUIRE(conv1_f16x3 == 0 || ((conv1_f16x3 == 1 || conv1_f16x3 == 2) && e->sub == 2),
+              "mst_encoder_set_precision: the f16x3 modes need the default 20-mel sub-bands (pool height 2)");
   e->conv1_f16x3 = conv1_f16x3;
   return MST_OK;
 }
@@ -1118,8 +1286,12 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
         attr16 = true;
       }
+      const bool both = e->conv1_f16x3 == 2;
+      if (both && !(taps && taps->pool1)) cp.out = nullptr;   // fp32 pool1 only when a tap asks for it
       hipLaunchKernelGGL((conv1_f16x3_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp,
-                         reinterpret_cast<const h16x8*>(e->w1frag16));
+                         reinterpret_cast<const h16x8*>(e->w1frag16),
+                         both ? reinterpret_cast<_Float16*>(ws + L.pool1_h16) : nullptr,
+                         both ? reinterpret_cast<_Float16*>(ws + L.pool1_l16) : nullptr);
       err = hipGetLastError();
     } else if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
       using C = CC<1, 2>;
@@ -1151,7 +1323,23 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     cp.tiles_c = (L.W2 + 1) / 2;
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     const int g = std::min(grid, ns * cp.sets_per_band);
-    hipError_t err = launch_conv<2, 2>(cp, g, st);
+    hipError_t err;
+    if (e->conv1_f16x3 == 2) {
+      constexpr size_t lds = (size_t)(kF16Steps * 4 * 2 * 64 + kConvWaves * 2 * 14 * 14) * 16;
+      static bool attr = false;
+      if (!attr) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 f16x3 attribute failed: %s", hipGetErrorString(err));
+        attr = true;
+      }
+      hipLaunchKernelGGL(conv2_f16x3_kernel, dim3(g), dim3(kConvThreads), lds, st, cp,
+                         reinterpret_cast<const h16x8*>(ws + L.pool1_h16), reinterpret_cast<const h16x8*>(ws + L.pool1_l16),
+                         reinterpret_cast<const h16x8*>(e->w2frag16));
+      err = hipGetLastError();
+    } else {
+      err = launch_conv<2, 2>(cp, g, st);
+    }
     if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 launch failed: %s", hipGetErrorString(err));
   }
   mark(3);

@@ -197,9 +197,13 @@ class HipEncoder:
         h = C.c_void_p()
         _lib.check(_lib.lib().mst_encoder_create(C.byref(h), C.byref(self.cfg), C.byref(w)), "mst_encoder_create")
         self._h = h
-        if conv1_precision not in ("fp32", "f16x3"):
-            raise ValueError("conv1_precision must be 'fp32' (exact, default) or 'f16x3' (split-precision f16 MFMA)")
-        _lib.check(_lib.lib().mst_encoder_set_precision(h, int(conv1_precision == "f16x3")), "mst_encoder_set_precision")
+        modes = {"fp32": 0, "f16x3": 1, "f16x3-all": 2}
+        if conv1_precision not in modes:
+            raise ValueError("conv precision must be 'fp32' (exact, default), 'f16x3' (conv1 on split-precision f16 MFMA) "
+                             "or 'f16x3-all' (conv1 and conv2)")
+        self.mode = modes[conv1_precision]
+        self._range_checked = self.mode != 2
+        _lib.check(_lib.lib().mst_encoder_set_precision(h, self.mode), "mst_encoder_set_precision")
         self._ws = None
         self.embed_dim = ae.attention_pooling.output_dim
         self.n_sub, self.split, self.freq_dim = ae.n_subbands, ae.split_size, ae.freq_dim
@@ -216,6 +220,13 @@ class HipEncoder:
         """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
         B, _, M, Fr = logmel.shape
         L = _lib.lib()
+        if not self._range_checked:   # conv2's f16 input must stay below 65504: check max(pool1) once (one host sync)
+            self._range_checked = True
+            _, t = self.forward(logmel[:1], feats[:1], taps=True)
+            mx = t["pool1"].abs().max().item()
+            if not mx < 3.0e4:
+                raise _lib.MstError(f"f16x3-all: conv1 activations reach {mx:.3g}, too close to the f16 range; use "
+                                    f"conv precision 'f16x3' (conv1 only) or 'fp32'")
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
         if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=logmel.device)

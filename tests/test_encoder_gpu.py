@@ -146,8 +146,9 @@ def test_config5_geometry_30s_256_mels():
     close(emb.cpu(), ref)
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-all"])
 @pytest.mark.parametrize("tag,T", [("default", 441000), ("default_short", 66150)])
-def test_conv1_f16x3_split_precision_meets_the_fp32_bar(tag, T):
+def test_conv_f16x3_split_precision_meets_the_fp32_bar(tag, T, mode):
     """Opt-in conv1 on the f16 matrix cores (3-term split): same goldens, same 1e-4 tolerance as the exact path;
     also reports how far it is from the exact-fp32 kernel."""
     g = np.load(os.path.join(G, "encoder.npz"))
@@ -158,7 +159,7 @@ def test_conv1_f16x3_split_precision_meets_the_fp32_bar(tag, T):
     with torch.no_grad():
         lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
         e32, t32 = model.hip_encoder().forward(lm, feats, taps=True)
-        model.conv1_precision = "f16x3"
+        model.conv1_precision = mode
         e16, t16 = model.hip_encoder().forward(lm, feats, taps=True)
         model.conv1_precision = "fp32"
     ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
@@ -170,5 +171,6 @@ def test_conv1_f16x3_split_precision_meets_the_fp32_bar(tag, T):
     close(e16.cpu(), g[f"{tag}.embedding"])
     d_pool = (t16["pool1"] - t32["pool1"]).abs().max().item() / t32["pool1"].abs().max().item()
     d_emb = (e16 - e32).abs().max().item() / e32.abs().max().item()
-    print(f"f16x3 vs exact fp32: pool1 {d_pool:.2e}, embedding {d_emb:.2e} (relative to max)")
-    assert d_pool < 2e-6 and d_emb < 1e-5
+    d_pin = (t16["pool_in"] - t32["pool_in"]).abs().max().item() / t32["pool_in"].abs().max().item()
+    print(f"{mode} vs exact fp32: pool1 {d_pool:.2e}, pool_in {d_pin:.2e}, embedding {d_emb:.2e} (relative to max)")
+    assert d_pool < 2e-6 and d_pin < 1e-5 and d_emb < 1e-5
