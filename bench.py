@@ -182,6 +182,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = t.item()
 
+    # opt-in split-precision mode, measured after (outside) the contract's timed region; the headline stays exact fp32
+    alt = None
+    if backend == "hip" and a.precision == "fp32" and not a.aug:
+        model.conv1_precision = "f16x3-all"
+        n_alt = max(5, a.steps // 2)
+        main_marks = len(marks)
+        try:
+            for _ in range(3):
+                step(False)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(n_alt):
+                step(False)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            alt = {"mode": "f16x3-all: conv1+conv2 on f16 MFMA with 3-term split precision, fp32 accumulate; embeddings "
+                           "within 1e-6 (rel. to max) of the exact-fp32 kernels, same 1e-4 parity tests",
+                   "value": round(world * a.triplets * n_alt / tb.item(), 3), "unit": "triplets/s",
+                   "ms_per_step": round(tb.item() / n_alt * 1e3, 4), "steps": n_alt}
+        except Exception as ex:  # e.g. activations too close to the f16 range: the mode refuses to run
+            alt = {"mode": "f16x3-all", "error": str(ex)[:200]}
+        model.conv1_precision = a.precision
+        del marks[main_marks:]
+
     msA = sum(m[0].elapsed_time(m[1]) for m in marks) / len(marks)
     msB = sum(m[1].elapsed_time(m[2]) for m in marks) / len(marks)
     if rank == 0:
@@ -237,6 +267,7 @@ def main():
                        "encoder_backend": backend, "conv1_precision": a.precision, "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
             "roofline": roof,
         }
+        out["alt"] = alt
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model.state_dict(), None, T)
         print(json.dumps(out), flush=True)

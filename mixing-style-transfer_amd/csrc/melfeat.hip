@@ -21,6 +21,10 @@
 #include <cmath>
 #include <vector>
 
+#ifndef MST_ABLATE
+#define MST_ABLATE 0   // timing-only builds: 1 no mel gather, 2 +no real-FFT split, 3 +no FFT passes, 4 +no global loads
+#endif
+
 namespace {
 
 constexpr int kWaves = 8;              // waves per workgroup
@@ -69,6 +73,7 @@ struct KParams {
   int frames_per_run, runs_per_clip, pstride;
   int vec_ok;  // 8-byte aligned float2 frame loads allowed
   int vec4_ok; // 16-byte aligned float4 stats loads allowed
+  int tile_bufs;  // 2: double-buffered output tile (one barrier per stem); 1: single (LDS-limited configs)
 };
 
 using namespace mstfft;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* __rest
         const float2 w = s_win[n];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          const float2 x = reinterpret_cast<const float2*>(xch + s0[f])[n];
+          const float2 x = MST_ABLATE >= 4 ? make_float2(0.001f * n, 0.002f * lane) : reinterpret_cast<const float2*>(xch + s0[f])[n];
           v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
         }
       }
@@ -127,12 +132,12 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* __rest
         }
       }
   }
-  Plan::template run<NF>(v, scr, s_tw, lane);
+  if (MST_ABLATE < 3) Plan::template run<NF>(v, scr, s_tw, lane);
 
   // real-FFT split: X[k] = E + W^k O with E,O from Z[k] and conj(Z[NC-k]); P = |X|^2
   const int mirror = (64 - lane) & 63;
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
+  for (int q = 0; q < (MST_ABLATE >= 2 ? 0 : Q); ++q) {
     auto reg = [](int qq) { return (qq % NBFL) * RL + qq / NBFL; };
     const float2 w = s_post[q * 64 + lane];
 #pragma unroll
@@ -163,7 +168,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* __rest
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = 0.f;
     const float* w = s_melw + p.goff[r] + lane;
-    const int n = p.glen[r];
+    const int n = MST_ABLATE >= 1 ? 0 : p.glen[r];
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
       const float wi = w[i * 64];
@@ -172,7 +177,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* __rest
       for (int f = 0; f < NF; ++f) acc[f] = fmaf(wi, reinterpret_cast<const float*>(scr + f * SCR)[k], acc[f]);
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) mel[f][r] = acc[f];
+    for (int f = 0; f < NF; ++f) mel[f][r] = acc[f] + (MST_ABLATE ? v[f][r].x + v[f][r + 2].y + reinterpret_cast<const float*>(scr + f * SCR)[lane] : 0.f);
   }
 }
 
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
   float2* s_post = s_tw + p.tw_count;                          // [NC]
   float2* s_scr = s_post + NC;                                 // [kWaves][SCR]
   float* s_melw = reinterpret_cast<float*>(s_scr + kWaves * SCR);  // [nnz padded to 4]
-  float* s_tile = s_melw + ((p.nnz + 3) & ~3);                 // [2*M][kTileStride]
+  float* s_tile0 = s_melw + ((p.nnz + 3) & ~3);                // [2][2*M][kTileStride] double-buffered output tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int work = mst::xcd_remap(blockIdx.x, gridDim.x);
@@ -229,6 +234,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) cr[s] = mid[s] = side[s] = 0.f;
+#pragma unroll 2
     for (int i = tid * 4; i < n_own; i += kThreads * 4) {
       float x[8][4];
       const bool full = (i + 3 < n_own);
@@ -332,6 +338,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 
 #pragma unroll 1
     for (int s = 0; s < 4; ++s) {
+      float* s_tile = s_tile0 + (p.tile_bufs == 2 ? (s & 1) : 0) * (2 * M * kTileStride);
       int frame[kFPW];
       bool fok[kFPW];
 #pragma unroll
@@ -390,6 +397,8 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) S[ss][ff][r] = (s == ss) ? sm[ff][r] : S[ss][ff][r];
       }
+      // one barrier per stem: the tile of stem s is complete; its flush below overlaps the FFTs of stem s+1 (other
+      // buffer), and buffer (s & 1) is written again only after the barrier of stem s+1, i.e. after this flush
       __syncthreads();
       if (p.logmel) {  // flush the stem's two channels: rows (c, band), kTF consecutive frames each
         const int f = tid % kTF, frame = fb + f;
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
           }
         }
       }
-      __syncthreads();
+      if (p.tile_bufs == 1) __syncthreads();  // single tile: the next stem overwrites it
     }
     // inter-stem masking for this wave's frames (mixing_utils.py:288-307)
 #pragma unroll
@@ -803,7 +812,12 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   const int nc = p->nc;
   const int nf = nf_of(p->n_fft);
   size_t lds = (size_t)(nc + p->tw_count + nc + kWaves * nf * (nc + nc / 8)) * sizeof(float2) +
-               (size_t)(((p->nnz + 3) & ~3) + 2 * p->n_mels * kTileStride) * sizeof(float);
+               (size_t)(((p->nnz + 3) & ~3) + 2 * 2 * p->n_mels * kTileStride) * sizeof(float);
+  kp.tile_bufs = 2;
+  if (lds > 160 * 1024) {  // fall back to a single output tile
+    lds -= (size_t)2 * p->n_mels * kTileStride * sizeof(float);
+    kp.tile_bufs = 1;
+  }
   // the reduction buffers alias the FFT scratch: kWaves*4*NB*64 + kWaves*12 floats must fit
   const size_t red_need = (size_t)(kWaves * 4 * p->nb * 64 + kWaves * 12) * sizeof(float);
   MST_REQUIRE(red_need <= (size_t)kWaves * nf * (nc + nc / 8) * sizeof(float2), "internal: reduction buffer");
