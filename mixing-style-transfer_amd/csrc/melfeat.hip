@@ -234,46 +234,55 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) cr[s] = mid[s] = side[s] = 0.f;
-#pragma unroll 2
-    for (int i = tid * 4; i < n_own; i += kThreads * 4) {
-      float x[8][4];
-      const bool full = (i + 3 < n_own);
+    // all loads of up to kIT iterations are issued before any arithmetic: the pass is latency-bound otherwise
+    constexpr int kIT = 2;
+    for (int base = tid * 4; base < (MST_ABLATE >= 5 ? 0 : n_own); base += kThreads * 4 * kIT) {
+      float x[kIT][8][4];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        const float* src = chan(c) + o_begin + i;
-        if (full && p.vec4_ok) {
-          const float4 q = *reinterpret_cast<const float4*>(src);
-          x[c][0] = q.x, x[c][1] = q.y, x[c][2] = q.z, x[c][3] = q.w;
-        } else {
+      for (int it = 0; it < kIT; ++it) {
+        const int i = base + it * kThreads * 4;
+        const bool full = (i + 3 < n_own);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) x[c][e] = (i + e < n_own) ? src[e] : piv[c];
+        for (int c = 0; c < 8; ++c) {
+          const float* src = chan(c) + o_begin + min(i, max(n_own - 1, 0));
+          if (full && p.vec4_ok) {
+            const float4 q = *reinterpret_cast<const float4*>(src);
+            x[it][c][0] = q.x, x[it][c][1] = q.y, x[it][c][2] = q.z, x[it][c][3] = q.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[it][c][e] = (i + e < n_own) ? src[e] : piv[c];
+          }
         }
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (i + e < n_own) {
-          float mL = 0.f, mR = 0.f;
+      for (int it = 0; it < kIT; ++it) {
+        const int i = base + it * kThreads * 4;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const float L = x[2 * s][e], R = x[2 * s + 1][e];
-            const float dL = L - piv[2 * s], dR = R - piv[2 * s + 1];
-            sq[2 * s] = fmaf(L, L, sq[2 * s]);
-            sq[2 * s + 1] = fmaf(R, R, sq[2 * s + 1]);
-            pk[2 * s] = fmaxf(pk[2 * s], fabsf(L));
-            pk[2 * s + 1] = fmaxf(pk[2 * s + 1], fabsf(R));
-            ds[2 * s] += dL;
-            ds[2 * s + 1] += dR;
-            dq[2 * s] = fmaf(dL, dL, dq[2 * s]);
-            dq[2 * s + 1] = fmaf(dR, dR, dq[2 * s + 1]);
-            cr[s] = fmaf(dL, dR, cr[s]);
-            const float sm = L + R, sd = L - R;
-            mid[s] = fmaf(sm, sm, mid[s]);
-            side[s] = fmaf(sd, sd, side[s]);
-            mL += L;  // python sum(): ((v + b) + d) + o
-            mR += R;
+        for (int e = 0; e < 4; ++e) {
+          if (i + e < n_own) {
+            float mL = 0.f, mR = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const float L = x[it][2 * s][e], R = x[it][2 * s + 1][e];
+              const float dL = L - piv[2 * s], dR = R - piv[2 * s + 1];
+              sq[2 * s] = fmaf(L, L, sq[2 * s]);
+              sq[2 * s + 1] = fmaf(R, R, sq[2 * s + 1]);
+              pk[2 * s] = fmaxf(pk[2 * s], fabsf(L));
+              pk[2 * s + 1] = fmaxf(pk[2 * s + 1], fabsf(R));
+              ds[2 * s] += dL;
+              ds[2 * s + 1] += dR;
+              dq[2 * s] = fmaf(dL, dL, dq[2 * s]);
+              dq[2 * s + 1] = fmaf(dR, dR, dq[2 * s + 1]);
+              cr[s] = fmaf(dL, dR, cr[s]);
+              const float sm = L + R, sd = L - R;
+              mid[s] = fmaf(sm, sm, mid[s]);
+              side[s] = fmaf(sd, sd, side[s]);
+              mL += L;  // python sum(): ((v + b) + d) + o
+              mR += R;
+            }
+            mix = fmaf(mL, mL, mix);
+            mix = fmaf(mR, mR, mix);
           }
-          mix = fmaf(mL, mL, mix);
-          mix = fmaf(mR, mR, mix);
         }
       }
     }
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
               const bool ok = lb_band[r] >= 0 && fok[ff];
-              const float lm = __log2f(mel[ff][r] + 1e-10f) * kLn2;
+              const float lm = MST_ABLATE >= 6 ? mel[ff][r] : __log2f(mel[ff][r] + 1e-10f) * kLn2;
               if (ok) {
                 s_tile[(c * M + lb_band[r]) * kTileStride + wave * kFPW + ff] = lm;
                 lsum += lm;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
           for (int j = 0; j < 4; ++j)
             if (j != ss) other = fmaxf(other, S[j][ff][r]);
           const float d = S[ss][ff][r] - other;
-          acc_mask[ss] += __frcp_rn(1.0f + __expf(d));  // sigmoid((0 - d) / 1)
+          if (MST_ABLATE < 6) acc_mask[ss] += __frcp_rn(1.0f + __expf(d));  // sigmoid((0 - d) / 1)
         }
       }
     }
