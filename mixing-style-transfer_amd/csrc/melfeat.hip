@@ -86,13 +86,16 @@ __device__ __forceinline__ float2 shfl2(float2 a, int src) {
 
 // mel power of NF frames of one channel, computed side by side (two independent FFT dependency chains per wave;
 // window, twiddles and mel weights are loaded once for both): returns this lane's NB band values per frame.
-template <int NFFT, int NB, int NF>
-__device__ __forceinline__ void frames_mel(const KParams& p, const float* __restrict__ xch, const int (&frame)[NF],
+// With hop == NFFT/4 the samples a frame "owns" for the waveform moments, [f*hop, (f+1)*hop), are elements
+// Q/2 .. Q/2 + Q/4 - 1 of every lane (float2 index lane + 64*q); RAW builds return them un-windowed in `raw`.
+template <int NFFT, int NB, int NF, bool RAW = false>
+__device__ __forceinline__ void frames_mel(const KParams& p, const float* const (&xchs)[NF], const int (&frame)[NF],
                                            int lane, const float2* s_win, const float2* s_tw, const float2* s_post,
                                            const float* s_melw, float2* scr, const int (&lb_start)[NB],
-                                           float (&mel)[NF][NB]) {
+                                           float (&mel)[NF][NB], float2 (*raw)[NFFT / 512] = nullptr) {
   constexpr int NC = NFFT / 2;
   constexpr int Q = NC / 64;
+  constexpr int NOWN = Q / 4;
   constexpr int SCR = NC + NC / 8;
   using Plan = FftPlan<NC>;
   constexpr int R0 = Plan::R0, RL = Plan::RL;
@@ -114,8 +117,12 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* __rest
         const float2 w = s_win[n];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          const float2 x = MST_ABLATE >= 4 ? make_float2(0.001f * n, 0.002f * lane) : reinterpret_cast<const float2*>(xch + s0[f])[n];
+          const float2 x = MST_ABLATE >= 4 ? make_float2(0.001f * n, 0.002f * lane) : reinterpret_cast<const float2*>(xchs[f] + s0[f])[n];
           v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
+          if constexpr (RAW) {
+            const int q = u + t * NBF0;  // compile-time after unrolling
+            if (q >= Q / 2 && q < Q / 2 + NOWN) raw[f][q - Q / 2] = x;
+          }
         }
       }
   } else {
@@ -128,7 +135,12 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* __rest
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const int i0 = s0[f] + 2 * n;
-          v[f][u * R0 + t] = make_float2(xch[reflect_idx(i0, p.T)] * w.x, xch[reflect_idx(i0 + 1, p.T)] * w.y);
+          const float2 x = make_float2(xchs[f][reflect_idx(i0, p.T)], xchs[f][reflect_idx(i0 + 1, p.T)]);
+          v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
+          if constexpr (RAW) {
+            const int q = u + t * NBF0;
+            if (q >= Q / 2 && q < Q / 2 + NOWN) raw[f][q - Q / 2] = x;
+          }
         }
       }
   }
@@ -362,13 +374,15 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
         for (int c = 0; c < 2; ++c) {
           float mel[kFPW][NB];
           if constexpr (NF == kFPW) {
-            frames_mel<NFFT, NB, kFPW>(p, chan(2 * s + c), frame, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, mel);
+            const float* const xs[kFPW] = {chan(2 * s + c), chan(2 * s + c)};
+            frames_mel<NFFT, NB, kFPW>(p, xs, frame, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, mel);
           } else {
 #pragma unroll 1
             for (int ff = 0; ff < kFPW; ++ff) {
               const int one[1] = {frame[ff]};
               float m1[1][NB];
-              frames_mel<NFFT, NB, 1>(p, chan(2 * s + c), one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
+              const float* const x1[1] = {chan(2 * s + c)};
+              frames_mel<NFFT, NB, 1>(p, x1, one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
 #pragma unroll
               for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -468,6 +482,211 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     float v = 0.f;
     for (int w = 0; w < kWaves; ++w) v += red2[w * 12 + tid];
     part[4 * M + tid] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Stage A, "stem per wave pair" layout for the standard configuration (hop == n_fft/4, n_mels <= 128, aligned
+// input).  Waves 2s and 2s+1 own stem s: a wave runs the L and the R FFT of ONE frame side by side (even / odd
+// frames of a 16-frame batch), so
+//   * per-channel and L/R cross moments come from the un-windowed samples the frame owns (no moment pass; consecutive
+//     frames of a wave overlap by half, the partner wave covers the rest: L1/L2 hits),
+//   * all 8 channels x 16 frames of log-mel land in one frame-major LDS tile and are flushed once per batch
+//     (2 barriers per batch instead of 8), the inter-stem masking is evaluated from that tile,
+//   * the mixture energy comes from a short float4 pass over the batch's samples (just loaded: cache-resident).
+// Writes the same partial records as melfeat_kernel (same finalise kernel).
+// ------------------------------------------------------------------------------------------
+template <int NFFT>
+__global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) {
+  constexpr int NB = 2, NC = NFFT / 2, NOWN = NFFT / 512;
+  constexpr int SCR1 = NC + NC / 8, SCR = 2 * SCR1;
+  constexpr float kLn2 = 0.69314718055994530942f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2* s_win = reinterpret_cast<float2*>(smem);
+  float2* s_tw = s_win + NC;
+  float2* s_post = s_tw + p.tw_count;
+  float2* s_scr = s_post + NC;                                    // [kWaves][SCR]
+  float* s_melw = reinterpret_cast<float*>(s_scr + kWaves * SCR);
+  float* s_tile = s_melw + ((p.nnz + 3) & ~3);                    // [kTF][8*M + 1]  log-mel, frame-major
+  const int M = p.M, TS = 8 * M + 1;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int work = mst::xcd_remap(blockIdx.x, gridDim.x);
+  const int clip = work / p.runs_per_clip, run = work % p.runs_per_clip;
+  const int f_begin = run * p.frames_per_run;
+  const int f_end = min(p.F, f_begin + p.frames_per_run);
+  {
+    const float2* gw = reinterpret_cast<const float2*>(p.window);
+    for (int i = tid; i < NC; i += kThreads) s_win[i] = gw[i];
+    for (int i = tid; i < p.tw_count; i += kThreads) s_tw[i] = p.tw[i];
+    for (int i = tid; i < NC; i += kThreads) s_post[i] = p.post[i];
+    for (int i = tid; i < p.nnz; i += kThreads) s_melw[i] = p.melw[i];
+  }
+  int lb_band[NB], lb_start[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const LaneBand q = p.lanebands[r * 64 + lane];
+    lb_band[r] = q.band, lb_start[r] = q.start;
+  }
+  auto chan = [&](int c) { return p.stem[c >> 1] + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T; };
+  float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
+  const int stem = wave >> 1, half = wave & 1;
+  const float* const xs[2] = {chan(2 * stem), chan(2 * stem + 1)};
+  const int o_begin = f_begin * p.hop;
+  const int o_end = (f_end == p.F) ? p.T : min(p.T, f_end * p.hop);
+  const int o_piv = min(o_begin, p.T - 1);
+  const float pvL = xs[0][o_piv], pvR = xs[1][o_piv];
+  float2* scr = s_scr + wave * SCR;
+
+  float acc_db[NB] = {0.f, 0.f}, acc_log = 0.f, acc_lin = 0.f;
+  float sqL = 0.f, sqR = 0.f, pkL = 0.f, pkR = 0.f, dsL = 0.f, dsR = 0.f, dqL = 0.f, dqR = 0.f;
+  float cr = 0.f, mid = 0.f, side = 0.f;
+  float mask[4] = {0.f, 0.f, 0.f, 0.f}, mixsq = 0.f;   // accumulated per thread in the tile phase
+  __syncthreads();
+
+  for (int fb = f_begin; fb < f_end; fb += kTF) {
+    // ---- phase A: every wave: 8 frames of its stem, L and R side by side
+#pragma unroll 1
+    for (int i = 0; i < kTF / 2; ++i) {
+      const int fr = fb + 2 * i + half;
+      if (fr >= f_end) break;  // wave-uniform
+      const int frame[2] = {fr, fr};
+      float mel[2][NB];
+      float2 raw[2][NOWN];
+      frames_mel<NFFT, NB, 2, true>(p, xs, frame, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, mel, raw);
+      float* trow = s_tile + (fr - fb) * TS + 2 * stem * M;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        if (lb_band[r] < 0) continue;
+        const float l0 = __log2f(mel[0][r] + 1e-10f) * kLn2, l1 = __log2f(mel[1][r] + 1e-10f) * kLn2;
+        trow[lb_band[r]] = l0;
+        trow[M + lb_band[r]] = l1;
+        acc_db[r] += l0 + l1;
+        acc_log += l0 + l1;
+        acc_lin += mel[0][r] + mel[1][r];
+      }
+      // waveform moments from the samples this frame owns
+#pragma unroll
+      for (int j = 0; j < NOWN; ++j)
+#pragma unroll
+        for (int comp = 0; comp < 2; ++comp) {
+          const int n = fr * p.hop + 2 * (lane + 64 * j) + comp;
+          const bool m = n < p.T;
+          const float L = m ? (comp ? raw[0][j].y : raw[0][j].x) : 0.f;
+          const float R = m ? (comp ? raw[1][j].y : raw[1][j].x) : 0.f;
+          const float dL = m ? L - pvL : 0.f, dR = m ? R - pvR : 0.f;
+          sqL = fmaf(L, L, sqL), sqR = fmaf(R, R, sqR);
+          pkL = fmaxf(pkL, fabsf(L)), pkR = fmaxf(pkR, fabsf(R));
+          dsL += dL, dsR += dR;
+          dqL = fmaf(dL, dL, dqL), dqR = fmaf(dR, dR, dqR);
+          cr = fmaf(dL, dR, cr);
+          mid = fmaf(L + R, L + R, mid);
+          side = fmaf(L - R, L - R, side);
+        }
+    }
+    __syncthreads();
+    // ---- phase B (all threads): flush the batch's log-mel, masking, mixture energy
+    const int nf = min(kTF, f_end - fb);
+    if (p.logmel) {
+      const int f = tid % kTF;
+      if (f < nf)
+        for (int row = tid / kTF; row < 8 * M; row += kThreads / kTF)   // row = ch * M + band
+          p.logmel[((size_t)clip * 8 * M + row) * p.F + fb + f] = s_tile[f * TS + row];
+    }
+    for (int e = tid; e < nf * M; e += kThreads) {  // (frame, band) pairs; 8 channel reads, conflict-free across bands
+      const int f = e / M, m = e - f * M;
+      const float* t = s_tile + f * TS + m;
+      float S[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)   // channel-mean mel power back from the log domain (abs. error ~1e-7 * power)
+        S[s] = 0.5f * ((__expf(t[(2 * s) * M]) - 1e-10f) + (__expf(t[(2 * s + 1) * M]) - 1e-10f));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        float other = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j != s) other = fmaxf(other, S[j]);
+        mask[s] += __frcp_rn(1.0f + __expf(S[s] - other));
+      }
+    }
+    {
+      const int b0 = fb * p.hop, b1 = (fb + nf == p.F) ? p.T : min(p.T, (fb + nf) * p.hop);
+      for (int i = b0 + tid * 4; i < b1; i += kThreads * 4) {
+        float x[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float* src = chan(c) + i;
+          if (i + 3 < b1) {
+            const float4 q = *reinterpret_cast<const float4*>(src);
+            x[c][0] = q.x, x[c][1] = q.y, x[c][2] = q.z, x[c][3] = q.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[c][e] = (i + e < b1) ? src[e] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float mL = ((x[0][e] + x[2][e]) + x[4][e]) + x[6][e];   // python sum(): ((v + b) + d) + o
+          const float mR = ((x[1][e] + x[3][e]) + x[5][e]) + x[7][e];
+          mixsq = fmaf(mL, mL, mixsq);
+          mixsq = fmaf(mR, mR, mixsq);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- reductions -> partial record (same slots as melfeat_kernel)
+  float* red = reinterpret_cast<float*>(s_scr);   // [kWaves][NB][64] band sums, then per-wave scalars
+#pragma unroll
+  for (int r = 0; r < NB; ++r) red[(wave * NB + r) * 64 + lane] = acc_db[r];
+  float* red2 = red + kWaves * NB * 64;           // [kWaves][24]
+  {
+    const float v[13] = {acc_log, acc_lin, sqL, sqR, dsL, dsR, dqL, dqR, cr, mid, side, mixsq, 0.f};
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const float r = mst::wave_sum(v[k]);
+      if (lane == 0) red2[wave * 24 + k] = r;
+    }
+    const float a = mst::wave_max(pkL), b = mst::wave_max(pkR);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float r = mst::wave_sum(mask[s]);
+      if (lane == 0) red2[wave * 24 + 14 + s] = r;
+    }
+    if (lane == 0) red2[wave * 24 + 12] = a, red2[wave * 24 + 13] = b;
+  }
+  __syncthreads();
+  for (int i = tid; i < 4 * NB * 64; i += kThreads) {
+    const int l = i & 63, r = (i >> 6) % NB, s = i / (64 * NB);
+    const int band = p.lanebands[r * 64 + l].band;
+    if (band >= 0) part[s * M + band] = red[((2 * s) * NB + r) * 64 + l] + red[((2 * s + 1) * NB + r) * 64 + l];
+  }
+  if (tid < 4) {  // per-stem scalars: waves 2s and 2s+1
+    const int s = tid;
+    const float* a = red2 + (2 * s) * 24;
+    const float* b = a + 24;
+    float* q = part + 4 * M;
+    q[S_LOGSUM + s] = a[0] + b[0];
+    q[S_LINSUM + s] = a[1] + b[1];
+    q[S_SQ + 2 * s] = a[2] + b[2], q[S_SQ + 2 * s + 1] = a[3] + b[3];
+    q[S_DSUM + 2 * s] = a[4] + b[4], q[S_DSUM + 2 * s + 1] = a[5] + b[5];
+    q[S_DSQ + 2 * s] = a[6] + b[6], q[S_DSQ + 2 * s + 1] = a[7] + b[7];
+    q[S_CROSS + s] = a[8] + b[8];
+    q[S_MID + s] = a[9] + b[9];
+    q[S_SIDE + s] = a[10] + b[10];
+    q[S_PEAK + 2 * s] = fmaxf(a[12], b[12]), q[S_PEAK + 2 * s + 1] = fmaxf(a[13], b[13]);
+    float mk = 0.f;
+    for (int w = 0; w < kWaves; ++w) mk += red2[w * 24 + 14 + s];
+    q[S_MASK + s] = mk;
+    q[S_PIVOT + 2 * s] = chan(2 * s)[o_piv], q[S_PIVOT + 2 * s + 1] = chan(2 * s + 1)[o_piv];
+  }
+  if (tid == 8) {
+    float mx = 0.f;
+    for (int w = 0; w < kWaves; ++w) mx += red2[w * 24 + 11];
+    part[4 * M + S_MIX] = mx;
+    part[4 * M + S_NSAMP] = (float)max(0, o_end - o_begin);
+    part[4 * M + S_NFRAME] = (float)max(0, f_end - f_begin);
   }
 }
 
@@ -833,6 +1052,25 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   MST_REQUIRE(lds <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds);
   const int grid = B * kp.runs_per_clip;
   hipError_t e = hipErrorInvalidValue;
+  // stem-per-wave-pair kernel for the standard configuration; the generic kernel covers everything else
+  const size_t lds_spw = (size_t)(nc + p->tw_count + nc + kWaves * 2 * (nc + nc / 8)) * sizeof(float2) +
+                         (size_t)(((p->nnz + 3) & ~3) + kTF * (8 * p->n_mels + 1)) * sizeof(float);
+  const bool spw = kp.vec_ok && kp.vec4_ok && p->hop * 4 == p->n_fft && p->n_mels <= 128 && p->nb == 2 &&
+                   (p->n_fft == 512 || p->n_fft == 1024) && lds_spw <= 160 * 1024 && !getenv("MST_MELFEAT_GENERIC");
+  if (spw) {
+    static size_t attr_spw[2] = {0, 0};
+    const int which = p->n_fft == 1024;
+    const void* fn = which ? reinterpret_cast<const void*>(melfeat_spw_kernel<1024>)
+                           : reinterpret_cast<const void*>(melfeat_spw_kernel<512>);
+    if (lds_spw > attr_spw[which]) {
+      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spw);
+      if (e != hipSuccess) return mst::fail(MST_EHIP, "melfeat_spw attribute failed: %s", hipGetErrorString(e));
+      attr_spw[which] = lds_spw;
+    }
+    if (which) hipLaunchKernelGGL((melfeat_spw_kernel<1024>), dim3(grid), dim3(kThreads), lds_spw, st, kp);
+    else hipLaunchKernelGGL((melfeat_spw_kernel<512>), dim3(grid), dim3(kThreads), lds_spw, st, kp);
+    e = hipGetLastError();
+  } else {
 #define MST_CASE(NF)                                                       \
   case NF:                                                                 \
     e = (p->nb == 2) ? launch_melfeat<NF, 2>(kp, grid, lds, st) : launch_melfeat<NF, 4>(kp, grid, lds, st); \
@@ -843,6 +1081,7 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
     MST_CASE(2048)
   }
 #undef MST_CASE
+  }
   if (e != hipSuccess) return mst::fail(MST_EHIP, "melfeat_kernel launch failed: %s", hipGetErrorString(e));
   if (feats) {
     FParams fp{kp.partials, feats, p->n_mels, F, T, kp.runs_per_clip, kp.pstride, p->detailed_bins, p->feat_dim};
