@@ -972,42 +972,61 @@ struct ProjParams {
   int B, C, E;
 };
 
-__global__ __launch_bounds__(256) void proj_kernel(const ProjParams p) {
+template <int MT>
+__global__ __launch_bounds__(512) void proj_kernel(const ProjParams p) {
+  // one workgroup = one 16-column tile of E x MT row tiles of clips; its 8 waves split K (split-K inside the
+  // workgroup, LDS reduce); every wave keeps 4 k-steps of loads in flight (the plain loop was latency-bound)
+  extern __shared__ float red[];  // [8 waves][MT * 4 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nt = blockIdx.x * 4 + wave, NTE = p.E / 16;
-  if (nt >= NTE) return;
+  const int nt = blockIdx.x, NTE = p.E / 16;
   const int kq = lane >> 4, i = lane & 15;
-  const int m0 = blockIdx.y * 128;
-  f32x4 acc[8];
+  const int m0 = blockIdx.y * (16 * MT);
+  f32x4 acc[MT];
+  const float* ap[MT];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float* ap[8];
-  bool okr[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int m = m0 + t * 16 + i;
-    okr[t] = m < p.B;
-    ap[t] = p.pooled + (size_t)(okr[t] ? m : 0) * p.C + kq;
+  for (int t = 0; t < MT; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ap[t] = p.pooled + (size_t)min(m0 + t * 16 + i, p.B - 1) * p.C + kq;   // rows past B are computed and dropped
   }
   const float* wf = p.wfrag + (size_t)nt * 64 + lane;
   const int steps = p.C / 4;
-  for (int s = 0; s < steps; ++s) {
-    const float bb = wf[(size_t)s * NTE * 64];
-    float a[8];
+  const int s0 = wave * steps / 8, s1 = (wave + 1) * steps / 8;
+  for (int sb = s0; sb < s1; sb += 4) {
+    float bb[4], a[4][MT];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) a[t] = okr[t] ? ap[t][4 * s] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int s = min(sb + u, s1 - 1);
+      bb[u] = (sb + u < s1) ? wf[(size_t)s * NTE * 64] : 0.f;   // a zero B fragment makes the padded step a no-op
 #pragma unroll
-    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], bb, acc[t], 0, 0, 0);
+      for (int t = 0; t < MT; ++t) a[u][t] = ap[t][4 * s];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][t], bb[u], acc[t], 0, 0, 0);
   }
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * (4 * MT) + t * 4 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
   const int e = nt * 16 + i;
   const float be = p.bias[e];
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
+  for (int t = wave; t < MT; t += 8) {  // wave w finalises tiles w, w+8, ...
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v += red[(w * (4 * MT) + t * 4 + r) * 64 + lane];
       const int m = m0 + t * 16 + 4 * kq + r;
-      if (m < p.B) p.emb[(size_t)m * p.E + e] = fmaxf(acc[t][r] + be, 0.f);
+      if (m < p.B) p.emb[(size_t)m * p.E + e] = fmaxf(v + be, 0.f);
     }
+  }
+}
+
+template <int MT>
+void launch_proj(const ProjParams& pj, int ygrid, hipStream_t st) {
+  hipLaunchKernelGGL((proj_kernel<MT>), dim3(pj.E / 16, ygrid), dim3(512), (size_t)8 * 4 * MT * 64 * sizeof(float), st, pj);
 }
 
 }  // namespace
@@ -1357,7 +1376,12 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     hipLaunchKernelGGL(attn_pool_kernel, dim3(B, slices), dim3(256), (size_t)((L.W2 + 3) & ~3) * sizeof(float), st, pp);
     MST_HIP_CHECK(hipGetLastError());
     ProjParams pj{pooled, e->projfrag, e->proj_b, emb, B, e->C, e->cfg.embed_dim};
-    hipLaunchKernelGGL(proj_kernel, dim3((e->cfg.embed_dim / 16 + 3) / 4, (B + 127) / 128), dim3(256), 0, st, pj);
+    const int mt_all = (B + 15) / 16;   // row tiles of clips
+    if (mt_all <= 1) launch_proj<1>(pj, 1, st);
+    else if (mt_all <= 2) launch_proj<2>(pj, 1, st);
+    else if (mt_all <= 3) launch_proj<3>(pj, 1, st);
+    else if (mt_all <= 5) launch_proj<5>(pj, 1, st);
+    else launch_proj<8>(pj, (B + 127) / 128, st);
     MST_HIP_CHECK(hipGetLastError());
   }
   mark(5);

@@ -729,12 +729,14 @@ __global__ __launch_bounds__(256) void melfeat_finalize_kernel(const FParams p) 
   const double k_db = 10.0 / log(10.0);
   for (int i = tid; i < 4 * M; i += 256) {
     double s = 0;
+#pragma unroll 8
     for (int r = 0; r < p.runs_per_clip; ++r) s += base[(size_t)r * p.pstride + i];
     band[i] = s * inv_n_db * k_db;  // mean over (2 ch, F) of 10*log10(mel + 1e-10)
   }
   if (tid < kNumScalars) {
     const bool is_max = tid >= S_PEAK && tid < S_PEAK + 8;
     double s = 0;
+#pragma unroll 8
     for (int r = 0; r < p.runs_per_clip; ++r) {
       const double v = base[(size_t)r * p.pstride + 4 * M + tid];
       s = is_max ? fmax(s, v) : s + v;
