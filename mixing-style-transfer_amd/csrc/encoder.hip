@@ -880,22 +880,20 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const AttnParams p) {
   for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int steps = p.C / 4;
   const float* wf = p.w1frag + (size_t)(wave * 4) * 64 + lane;
-  float a_nx = ok ? xa[0] : 0.f;
-  float b_nx[4];
+  // 4 k-steps of loads in flight (20 independent loads) before their 16 MFMAs: the loop is latency-bound otherwise
+  for (int sb = 0; sb < steps; sb += 4) {
+    float a[4], bb[4][4];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) b_nx[n] = wf[n * 64];
-  for (int s = 0; s < steps; ++s) {
-    const float a = a_nx;
-    float bb[4];
+    for (int u = 0; u < 4; ++u) {
+      const int s = min(sb + u, steps - 1);
+      a[u] = (ok && sb + u < steps) ? xa[(size_t)s * 4 * p.W] : 0.f;   // a zero A fragment makes a padded step a no-op
 #pragma unroll
-    for (int n = 0; n < 4; ++n) bb[n] = b_nx[n];
-    if (s + 1 < steps) {  // software prefetch of the next k-step
-      a_nx = ok ? xa[(size_t)(s + 1) * 4 * p.W] : 0.f;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) b_nx[n] = wf[((size_t)(s + 1) * 16 + n) * 64];
+      for (int n = 0; n < 4; ++n) bb[u][n] = wf[((size_t)s * 16 + n) * 64];
     }
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb[n], acc[n], 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bb[u][n], acc[n], 0, 0, 0);
   }
   // rows 4*kq + r of this M-tile live in lane group kq; columns (wave*4 + n)*16 + i
 #pragma unroll

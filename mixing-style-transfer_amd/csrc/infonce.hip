@@ -30,13 +30,24 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* emb, con
   __syncthreads();
   float* s = sim + (size_t)blockIdx.x * N;
   float mx = -INFINITY;
-  for (int j = wave; j < N; j += 4) {  // one wave per column: coalesced dot product
-    const float* ej = emb + (size_t)j * D;
-    float a = 0.f;
-    for (int d = lane; d < D; d += 64) a = fmaf(srow[d], ej[d], a);
-    a = mst::wave_sum(a) * inv_norm[j] * inv_tau;
-    if (lane == 0) s[j] = a;
-    mx = fmaxf(mx, a);
+  for (int j0 = wave * 4; j0 < N; j0 += 16) {  // one wave = 4 columns at a time: 4 independent coalesced dot products
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* ej[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ej[u] = emb + (size_t)min(j0 + u, N - 1) * D;
+    for (int d = lane; d < D; d += 64) {
+      const float x = srow[d];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a[u] = fmaf(x, ej[u][d], a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u;
+      if (j >= N) break;
+      const float v = mst::wave_sum(a[u]) * inv_norm[j] * inv_tau;
+      if (lane == 0) s[j] = v;
+      mx = fmaxf(mx, v);
+    }
   }
   if (lane == 0) red[wave] = mx;
   __syncthreads();
