@@ -653,29 +653,46 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
     for (int t = 0; t < MT; ++t)
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int st = 0; st < kF16Steps; ++st) {
-      h16x8 ah[MT], al[MT], bh[NT], bl[NT];
+    {
+      // fragments of k-step st+1 are read from LDS while the 30 MFMAs of step st run (double-buffered registers)
+      h16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
-        bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
+        bh[0][n] = wres[(n * 2 + 0) * 64 + lane];
+        bl[0][n] = wres[(n * 2 + 1) * 64 + lane];
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        ah[t] = phi[abase[t] + toff[st]];
-        al[t] = plo[abase[t] + toff[st]];
+        ah[0][t] = phi[abase[t] + toff[0]];
+        al[0][t] = plo[abase[t] + toff[0]];
       }
 #pragma unroll
-      for (int k = 0; k < 5; ++k) prefetch_piece(st * 5 + k);   // 64 row loads of the next tile over 13 steps
+      for (int st = 0; st < kF16Steps; ++st) {
+        const int cu = st & 1, nx = cu ^ 1;
+        if (st + 1 < kF16Steps) {
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
+          for (int n = 0; n < NT; ++n) {
+            bh[nx][n] = wres[(((st + 1) * NT + n) * 2 + 0) * 64 + lane];
+            bl[nx][n] = wres[(((st + 1) * NT + n) * 2 + 1) * 64 + lane];
+          }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);  // small terms first
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
+          for (int t = 0; t < MT; ++t) {
+            ah[nx][t] = phi[abase[t] + toff[st + 1]];
+            al[nx][t] = plo[abase[t] + toff[st + 1]];
+          }
         }
+#pragma unroll
+        for (int k = 0; k < 5; ++k) prefetch_piece(st * 5 + k);   // 64 row loads of the next tile over 13 steps
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);  // small terms first
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bl[cu][n], acc[t][n], 0, 0, 0);
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
+      }
     }
     {
       const int j = lane & 15, g = lane >> 4;
