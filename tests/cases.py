@@ -127,3 +127,31 @@ def make_state_dict(cfg, seed=42, feature_dim=64):
 def checksum(x: torch.Tensor):
     x = x.double()
     return [float(x.sum()), float((x * x).sum())]
+
+
+def pseudo_separate(x2: torch.Tensor, sample_rate: int = 44100) -> torch.Tensor:
+    """Fixed deterministic 4-way split of a stereo mix (2, T) -> stems (8, T), used where the reference would call
+    SCNet (absent: BASELINE.md section 4).  bass = LP 200 Hz, drums = HP 4 kHz, vocals = 0.6 * mid of the rest
+    (mono), other = the remainder; the stems sum back to the mix.  scipy float64 filters, cast to fp32."""
+    import numpy as np
+    from scipy.signal import butter, sosfilt
+    x = x2.double().numpy()
+    bass = sosfilt(butter(2, 200, btype="low", fs=sample_rate, output="sos"), x, axis=-1)
+    drums = sosfilt(butter(2, 4000, btype="high", fs=sample_rate, output="sos"), x, axis=-1)
+    rest = x - bass - drums
+    mid = 0.6 * rest.mean(axis=0, keepdims=True).repeat(2, axis=0)
+    other = rest - mid
+    stems = np.concatenate([mid, bass, drums, other], axis=0)   # vocals, bass, drums, other
+    return torch.from_numpy(stems.astype(np.float32))
+
+
+def song_a_clips():
+    """The two 10 s crops of the reference's assets/song_A.wav (samples 0 and 220538; BASELINE configs[0]) from the
+    committed int16 fixture, pseudo-separated: (2, 8, 441000) fp32."""
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "song_a_crops.npz"))
+    out = []
+    for k in ("crop0", "crop1"):
+        x = torch.from_numpy(g[k].astype(np.float32) / 32768.0)   # (2, 441000)
+        out.append(pseudo_separate(x))
+    return torch.stack(out, 0)

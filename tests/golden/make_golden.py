@@ -207,8 +207,37 @@ def gen_augment():
     np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
 
 
+def gen_song_a():
+    """BASELINE configs[0]: two 10 s crops of assets/song_A.wav (the reference's own asset; data, stored as int16),
+    fixed pseudo-separation in place of SCNet, reference features + log-mel + embeddings."""
+    import wave
+    with wave.open("/root/reference/assets/song_A.wav", "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (2, 2, 44100)
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, 2).T.copy()
+    crops = {"crop0": pcm[:, 0:441000], "crop1": pcm[:, 220538:220538 + 441000]}
+    np.savez_compressed(os.path.join(HERE, "song_a_crops.npz"), **crops)
+    x = cases.song_a_clips()
+    out = {"in_checksum": np.array(cases.checksum(x))}
+    fe = ref_mu.MixingFeatureExtractor()
+    feats = torch.stack([fe.extract_all_features(stems_dict(x[b])) for b in range(2)], 0)
+    out["features"] = feats.numpy()
+    cfg = cases.CFG_DEFAULT
+    m = ref_model.MixingStyleEncoder(channels=8, feature_dim=64, **cfg).eval()
+    full = dict(m.state_dict())
+    full.update(cases.make_state_dict(cfg, seed=42))
+    m.load_state_dict(full, strict=True)
+    with torch.no_grad():
+        lm = m.audio_encoder.mel_preprocessor(stems_dict(x))
+        emb = m(stems_dict(x), feats)
+    idx = sample_idx(lm.numel(), 8192, 7)
+    out["logmel_idx"], out["logmel_samples"] = idx, lm.flatten()[idx].numpy()
+    out["logmel_rowsum"] = lm.double().sum(-1).numpy()
+    out["embedding"] = emb.numpy()
+    np.savez_compressed(os.path.join(HERE, "song_a.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fbanks", "features", "logmel", "encoder", "infonce", "augment"]
+    which = sys.argv[1:] or ["fbanks", "features", "logmel", "encoder", "infonce", "augment", "song_a"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -174,3 +174,28 @@ def test_conv_f16x3_split_precision_meets_the_fp32_bar(tag, T, mode):
     d_pin = (t16["pool_in"] - t32["pool_in"]).abs().max().item() / t32["pool_in"].abs().max().item()
     print(f"{mode} vs exact fp32: pool1 {d_pool:.2e}, pool_in {d_pin:.2e}, embedding {d_emb:.2e} (relative to max)")
     assert d_pool < 2e-6 and d_pin < 1e-5 and d_emb < 1e-5
+
+
+def test_song_a_real_music_end_to_end():
+    """BASELINE configs[0] on the GPU: real music through stage A + HIP encoder vs the reference goldens (bs=2)."""
+    from test_melfeat_gpu import check_feats, check_logmel
+    g = np.load(os.path.join(G, "song_a.npz"))
+    x = cases.song_a_clips()
+    model, sd = build_model(cases.CFG_DEFAULT)
+    from mst_amd.mixing_utils import MixingFeatureExtractor
+    stems = omel.tensor_to_stems_dict(x.cuda())
+    feats, lm = MixingFeatureExtractor().features_and_logmel(stems)
+    check_feats(feats.cpu(), g["features"])
+    check_logmel(lm.cpu(), omel.logmel(x), x=x)
+    idx = torch.from_numpy(g["logmel_idx"])
+    d = ((lm.cpu().flatten()[idx] - torch.from_numpy(g["logmel_samples"])).abs() /
+         torch.from_numpy(g["logmel_samples"]).abs().clamp(min=1.0))
+    print(f"song_A log-mel vs reference samples: max {d.max().item():.2e}, 99.9th pct {d.quantile(0.999).item():.2e}, "
+          f"mean {d.mean().item():.2e}")
+    with torch.no_grad():
+        emb = model(stems, feats)
+        model.conv1_precision = "f16x3-all"
+        emb16 = model(stems, feats)
+        model.conv1_precision = "fp32"
+    close(emb.cpu(), g["embedding"], 2e-4)
+    close(emb16.cpu(), g["embedding"], 2e-4)

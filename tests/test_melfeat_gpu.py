@@ -36,17 +36,27 @@ def scaled_err(a, ref):
 
 def check_logmel(lm, ref, tol=1e-4, x=None, cfg=None):
     """|gpu - ref| <= tol * max(1, |ref|).  When the input x is given the bound is made principled for
-    ill-conditioned inputs (e.g. a large DC offset puts every fp32 FFT's rounding floor near 1e-4 of the weak bins):
-    the GPU must be within tol of the float64-evaluated oracle, and within tol + (the fp32 oracle's own error
-    against float64) of the fp32 oracle."""
+    ill-conditioned inputs: bins that sit > ~130 dB below the frame's spectral peak (a low-passed bass stem, a large DC
+    offset) carry the fp32 FFT's rounding noise inside log(mel + 1e-10) in ANY fp32 implementation -- the reference's
+    own CPU result is then up to 4e-3 away from the float64 result (real music, tests/golden/song_a.npz).  So:
+      * where the fp32 oracle is itself within 0.2*tol of the float64-evaluated oracle: strict |gpu - oracle32| <= tol;
+      * everywhere: the GPU is no further from float64 than the fp32 oracle is (max: 1.5x + tol, mean: 2x + tol/100)."""
     e32 = scaled_err(lm, ref)
     if x is None:
         assert e32 <= tol, f"log-mel max scaled err {e32:.3e}"
         return
     ref64 = omel.logmel(x.double(), *(cfg or ()))
-    e64, eref = scaled_err(lm, ref64), scaled_err(ref, ref64)
-    assert e64 <= tol, f"log-mel err vs float64 oracle {e64:.3e}"
-    assert e32 <= tol + eref, f"log-mel err vs fp32 oracle {e32:.3e} (oracle's own fp32 error {eref:.3e})"
+    den = ref64.abs().clamp(min=1.0)
+    g64 = (lm.double() - ref64).abs() / den
+    r64 = (ref.double() - ref64).abs() / den
+    g32 = (lm.double() - ref.double()).abs() / ref.double().abs().clamp(min=1.0)
+    well = r64 <= 0.2 * tol
+    assert well.float().mean().item() > 0.5, "oracle ill-conditioned almost everywhere?"
+    assert g32[well].max().item() <= tol, f"log-mel err vs fp32 oracle on well-conditioned bins {g32[well].max().item():.3e}"
+    assert g64.max().item() <= 1.5 * r64.max().item() + tol, \
+        f"log-mel max err vs float64 {g64.max().item():.3e} (fp32 oracle's own: {r64.max().item():.3e})"
+    assert g64.mean().item() <= 2.0 * r64.mean().item() + tol / 100, \
+        f"log-mel mean err vs float64 {g64.mean().item():.3e} (fp32 oracle's own: {r64.mean().item():.3e})"
 
 
 def check_feats(f, ref, rtol=1e-4, atol=2e-4):

@@ -176,3 +176,17 @@ def test_augment_single_effects():
     close(oaug.compress(x).numpy()[:, :4096], g["compress.samples"], rtol=1e-6, atol=1e-8)
     torch.manual_seed(123)
     close(oaug.reverb(x, oaug.make_ir(44100)).numpy()[:, :4096], g["reverb.out_head"], rtol=1e-5, atol=1e-6)
+
+
+def test_song_a_real_music_config0():
+    """BASELINE configs[0]: real music (two 10 s crops of the reference's assets/song_A.wav, pseudo-separated)."""
+    g = load("song_a.npz")
+    x = cases.song_a_clips()
+    assert tuple(x.shape) == (2, 8, 441000)
+    close(cases.checksum(x), g["in_checksum"], rtol=1e-12, atol=0)
+    close(ofeat.extract_all_features(x).numpy(), g["features"], atol=2e-5)
+    lm = omel.logmel(x)
+    close(lm.flatten()[torch.from_numpy(g["logmel_idx"])].numpy(), g["logmel_samples"], rtol=1e-5, atol=1e-5)
+    sd = cases.make_state_dict(cases.CFG_DEFAULT, seed=42)
+    emb = oenc.encoder_from_logmel(sd, lm, torch.from_numpy(g["features"]))
+    close(emb.numpy(), g["embedding"], rtol=1e-4, atol=1e-5 * np.abs(g["embedding"]).max())
