@@ -83,7 +83,8 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[NF][NC / 64], float2* scr, 
     if constexpr (NS > 1) {
 #pragma unroll
       for (int t = 1; t < R; ++t) {
-        const float2 w = tw[(u * (R - 1) + (t - 1)) * 64 + lane];
+        // (lane + 64 u) % NS == lane % NS when NS divides 64: those passes store one row per t, not per (u, t)
+        const float2 w = tw[((NS <= 64 ? 0 : u) * (R - 1) + (t - 1)) * 64 + lane];
 #pragma unroll
         for (int f = 0; f < NF; ++f) v[f][u * R + t] = cmul(v[f][u * R + t], w);
       }
@@ -110,6 +111,9 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[NF][NC / 64], float2* scr, 
 // windowed input), RL the last (fixes the register order of the spectrum).
 template <int NC>
 struct FftPlan;
+// rows of 64 twiddles a pass contributes to the table
+constexpr int tw_rows(int NC, int R, int NS) { return NS == 1 ? 0 : (NS <= 64 ? 1 : NC / R / 64) * (R - 1); }
+
 template <>
 struct FftPlan<256> {
   static constexpr int R0 = 4, RL = 4;
@@ -136,13 +140,13 @@ struct FftPlan<512> {
 template <>
 struct FftPlan<1024> {
   static constexpr int R0 = 8, RL = 4;
-  static constexpr int TW = 2 * 7 * 64 + 4 * 3 * 64 + 4 * 3 * 64;
+  static constexpr int TW = 7 * 64 + 3 * 64 + 4 * 3 * 64;
   template <int NF>
   static __device__ __forceinline__ void run(float2 (&v)[NF][16], float2* scr, const float2* tw, int lane) {
     fft_pass<1024, 8, 1, true, false, NF>(v, scr, tw, lane);
     fft_pass<1024, 8, 8, false, false, NF>(v, scr, tw, lane);
-    fft_pass<1024, 4, 64, false, false, NF>(v, scr, tw + 2 * 7 * 64, lane);
-    fft_pass<1024, 4, 256, false, true, NF>(v, scr, tw + 2 * 7 * 64 + 4 * 3 * 64, lane);
+    fft_pass<1024, 4, 64, false, false, NF>(v, scr, tw + 7 * 64, lane);
+    fft_pass<1024, 4, 256, false, true, NF>(v, scr, tw + 7 * 64 + 3 * 64, lane);
   }
 };
 
@@ -178,7 +182,7 @@ __device__ inline void fill_twiddles(float2* tw, int tid, int nthreads) {
   for (int ps = 0; ps < PL::N; ++ps) {
     const int R = PL::R[ps], NS = PL::NS[ps];
     if (NS == 1) continue;
-    const int nbf = NC / R / 64, cnt = nbf * (R - 1) * 64;
+    const int nbf = NS <= 64 ? 1 : NC / R / 64, cnt = nbf * (R - 1) * 64;
     for (int e = tid; e < cnt; e += nthreads) {
       const int lane = e & 63, t = (e >> 6) % (R - 1) + 1, u = (e >> 6) / (R - 1);
       const int k = (lane + 64 * u) % NS;

@@ -64,11 +64,12 @@ struct KParams {
   float* partials;
   const float* window;
   const float2* tw;
+  const float2* tw2;         // twiddles of the n_fft-point complex FFT (frame-pair packing, n_fft <= 1024)
   const float2* post;
   const float* melw;
   const LaneBand* lanebands;  // [NB][64]
   int B, T, F, M, hop;
-  int tw_count, nnz;         // nnz = floats in the padded weight table melw[slot][i][lane]
+  int tw_count, tw2_count, nnz;  // nnz = floats in the padded weight table melw[slot][i][lane]
   int glen[4], goff[4];      // per band slot r: uniform gather length (max support over lanes) and table offset
   int frames_per_run, runs_per_clip, pstride;
   int vec_ok;  // 8-byte aligned float2 frame loads allowed
@@ -193,6 +194,108 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* const 
   }
 }
 
+// max over the wave of an unsigned value, returned in an SGPR: 4 DPP steps inside each row of 16 lanes
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then 4 readlanes.  No LDS traffic.
+__device__ __forceinline__ unsigned wave_umax_uniform(unsigned m) {
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true));
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true));
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, true));
+  m = max(m, (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x140, 0xF, 0xF, true));
+  const unsigned r0 = __builtin_amdgcn_readlane((int)m, 0), r1 = __builtin_amdgcn_readlane((int)m, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane((int)m, 32), r3 = __builtin_amdgcn_readlane((int)m, 48);
+  return max(max(r0, r1), max(r2, r3));
+}
+
+// Two real frames as the real and imaginary part of ONE NFFT-point complex FFT:
+//   z = a + i s b,  A[k] = (Z[k] + conj Z[N-k]) / 2,  s B[k] = (Z[k] - conj Z[N-k]) / (2i).
+// The kernels pair the L and the R channel of the same stem and frame.  Unlike the even/odd-sample packing
+// (half-length FFT + twiddled split, still used for n_fft = 2048) the split cancels nothing large: the cross-talk
+// into A[k] is eps * |s B[k]| -- the SAME bin of the partner -- and s, an exact power of two, equalises the two
+// frames' energies first, so each channel's error stays relative to its own level (the noise that remains is the
+// complex FFT's own rounding, which any fp32 FFT of that frame carries).  An all-zero frame returns exact zeros.
+// RAW: also return the un-windowed samples the frames own ([f*hop, (f+1)*hop): elements Q/2 .. Q/2+Q/4-1) as (a, b).
+template <int NFFT, int NB, bool RAW>
+__device__ __forceinline__ void frames_mel_cplx(const KParams& p, const float* __restrict__ xa,
+                                                const float* __restrict__ xb, int fA, int fB, int lane,
+                                                const float* s_winf, const float2* s_tw2, const float* s_melw,
+                                                float2* scr, const int (&lb_start)[NB], float (&mel)[2][NB],
+                                                float2 (*raw)) {
+  constexpr int NC = NFFT, Q = NC / 64, NOWN = Q / 4;
+  using Plan = FftPlan<NC>;
+  constexpr int R0 = Plan::R0, RL = Plan::RL;
+  constexpr int NBF0 = NC / R0 / 64, STR0 = NC / R0, NBFL = NC / RL / 64;
+  constexpr int PB_OFF = NFFT / 2 + 4;   // float offset of the second power spectrum inside the scratch
+  float2 v[1][Q];
+  const int sA = fA * p.hop - NFFT / 2, sB = fB * p.hop - NFFT / 2;
+  const bool interior = sA >= 0 && sB >= 0 && sA + NFFT <= p.T && sB + NFFT <= p.T;
+  float ma = 0.f, mb = 0.f;   // max |a w|, max |b w| of this lane
+#pragma unroll
+  for (int u = 0; u < NBF0; ++u)
+#pragma unroll
+    for (int t = 0; t < R0; ++t) {
+      const int n = lane + 64 * u + t * STR0;
+      const float w = s_winf[n];
+      float a, b;
+      if (MST_ABLATE >= 4) a = 0.001f * n, b = 0.002f * lane;
+      else if (interior) a = xa[sA + n], b = xb[sB + n];
+      else a = xa[reflect_idx(sA + n, p.T)], b = xb[reflect_idx(sB + n, p.T)];
+      const float aw = a * w, bw = b * w;
+      ma = fmaxf(ma, fabsf(aw)), mb = fmaxf(mb, fabsf(bw));
+      v[0][u * R0 + t] = make_float2(aw, bw);
+      if constexpr (RAW) {
+        const int q = u + t * NBF0;  // compile-time after unrolling
+        if (q >= Q / 2 && q < Q / 2 + NOWN) raw[q - Q / 2] = make_float2(a, b);
+      }
+    }
+  // wave-uniform peak magnitudes (as raw bits; non-negative floats order like unsigned ints) -> scale exponent
+  const unsigned ua = wave_umax_uniform(__float_as_uint(ma)), ub = wave_umax_uniform(__float_as_uint(mb));
+  int sh = 0;
+  if (ua != 0u && ub != 0u) sh = max(-40, min(40, (int)(ua >> 23) - (int)(ub >> 23)));
+  if (sh != 0) {   // scalar branch
+    const float sc = __uint_as_float((unsigned)(127 + sh) << 23);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[0][q].y *= sc;
+  }
+  const float ia = ua != 0u ? 1.0f : 0.f;
+  const float ib = ub != 0u ? __uint_as_float((unsigned)(127 - 2 * sh) << 23) : 0.f;
+  if (MST_ABLATE < 3) Plan::template run<1>(v, scr, s_tw2, lane);
+  float* PA = reinterpret_cast<float*>(scr);
+  float* PB = PA + PB_OFF;
+  const int mirror = (64 - lane) & 63;
+  auto reg = [](int qq) { return (qq % NBFL) * RL + qq / NBFL; };
+#pragma unroll
+  for (int q = 0; q < (MST_ABLATE >= 2 ? 0 : Q / 2); ++q) {
+    const float2 a = v[0][reg(q)];
+    const float2 bo = shfl2(v[0][reg(Q - 1 - q)], mirror);
+    const float2 bs = v[0][reg((Q - q) % Q)];
+    const float2 b = lane == 0 ? bs : bo;
+    const float ar = 0.5f * (a.x + b.x), ai = 0.5f * (a.y - b.y);   // A[k]
+    const float br = 0.5f * (a.y + b.y), bi = -0.5f * (a.x - b.x);  // s B[k]
+    PA[lane + 64 * q] = (ar * ar + ai * ai) * ia;
+    PB[lane + 64 * q] = (br * br + bi * bi) * ib;
+  }
+  if (lane == 0) {
+    const float2 z = v[0][reg(Q / 2)];   // bin NFFT/2: Z = A + i s B with both real
+    PA[NFFT / 2] = z.x * z.x * ia;
+    PB[NFFT / 2] = z.y * z.y * ib;
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    float a0 = 0.f, a1 = 0.f;
+    const float* w = s_melw + p.goff[r] + lane;
+    const int n = MST_ABLATE >= 1 ? 0 : p.glen[r];
+#pragma unroll 4
+    for (int i = 0; i < n; ++i) {
+      const float wi = w[i * 64];
+      const int k = min(lb_start[r] + i, NFFT / 2);
+      a0 = fmaf(wi, PA[k], a0);
+      a1 = fmaf(wi, PB[k], a1);
+    }
+    mel[0][r] = a0 + (MST_ABLATE ? v[0][r].x + PA[lane] : 0.f);
+    mel[1][r] = a1 + (MST_ABLATE ? v[0][r + 2].y + PB[lane] : 0.f);
+  }
+}
+
 template <int NFFT, int NB>
 __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
   constexpr int NC = NFFT / 2;
@@ -200,10 +303,12 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
   constexpr int SCR = NF * (NC + NC / 8);    // padded float2 per wave
   constexpr float kLn2 = 0.69314718055994530942f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2* s_win = reinterpret_cast<float2*>(smem);           // [NC] float2 = window pairs
-  float2* s_tw = s_win + NC;                                   // [tw_count]
-  float2* s_post = s_tw + p.tw_count;                          // [NC]
-  float2* s_scr = s_post + NC;                                 // [kWaves][SCR]
+  constexpr bool PAIR = NFFT <= 1024;        // frame-pair packed full-length FFT (see frames_mel_pair)
+  const int twn = PAIR ? p.tw2_count : p.tw_count;
+  float2* s_win = reinterpret_cast<float2*>(smem);           // [NC] float2 = window pairs = [NFFT] floats
+  float2* s_tw = s_win + NC;                                   // [twn]
+  float2* s_post = s_tw + twn;                                 // [NC] (even/odd packing only)
+  float2* s_scr = s_post + (PAIR ? 0 : NC);                    // [kWaves][SCR]
   float* s_melw = reinterpret_cast<float*>(s_scr + kWaves * SCR);  // [nnz padded to 4]
   float* s_tile0 = s_melw + ((p.nnz + 3) & ~3);                // [2][2*M][kTileStride] double-buffered output tile
 
@@ -218,8 +323,10 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
   {
     const float2* gw = reinterpret_cast<const float2*>(p.window);
     for (int i = tid; i < NC; i += kThreads) s_win[i] = gw[i];
-    for (int i = tid; i < p.tw_count; i += kThreads) s_tw[i] = p.tw[i];
-    for (int i = tid; i < NC; i += kThreads) s_post[i] = p.post[i];
+    const float2* gt = PAIR ? p.tw2 : p.tw;
+    for (int i = tid; i < twn; i += kThreads) s_tw[i] = gt[i];
+    if (!PAIR)
+      for (int i = tid; i < NC; i += kThreads) s_post[i] = p.post[i];
     for (int i = tid; i < p.nnz; i += kThreads) s_melw[i] = p.melw[i];
   }
   int lb_band[NB], lb_start[NB];
@@ -370,25 +477,41 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
       }
       if (fok[0]) {  // wave-uniform
         float sm[kFPW][NB];
+        float melall[2][kFPW][NB];   // [channel][frame slot][band slot]
+        if constexpr (PAIR) {
 #pragma unroll 1
-        for (int c = 0; c < 2; ++c) {
-          float mel[kFPW][NB];
-          if constexpr (NF == kFPW) {
-            const float* const xs[kFPW] = {chan(2 * s + c), chan(2 * s + c)};
-            frames_mel<NFFT, NB, kFPW>(p, xs, frame, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, mel);
-          } else {
-#pragma unroll 1
-            for (int ff = 0; ff < kFPW; ++ff) {
-              const int one[1] = {frame[ff]};
-              float m1[1][NB];
-              const float* const x1[1] = {chan(2 * s + c)};
-              frames_mel<NFFT, NB, 1>(p, x1, one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
+          for (int ff = 0; ff < kFPW; ++ff) {
+            float m2[2][NB];
+            frames_mel_cplx<NFFT, NB, false>(p, chan(2 * s), chan(2 * s + 1), frame[ff], frame[ff], lane,
+                                             reinterpret_cast<const float*>(s_win), s_tw, s_melw, scr, lb_start, m2,
+                                             nullptr);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
               for (int r = 0; r < NB; ++r)
 #pragma unroll
-                for (int f2 = 0; f2 < kFPW; ++f2) mel[f2][r] = (f2 == ff) ? m1[0][r] : mel[f2][r];
-            }
+                for (int f2 = 0; f2 < kFPW; ++f2) melall[c][f2][r] = (f2 == ff) ? m2[c][r] : melall[c][f2][r];
           }
+        } else {
+#pragma unroll 1
+          for (int cf = 0; cf < 2 * kFPW; ++cf) {
+            const int c = cf / kFPW, ff = cf % kFPW;
+            const int one[1] = {frame[ff]};
+            float m1[1][NB];
+            const float* const x1[1] = {chan(2 * s + c)};
+            frames_mel<NFFT, NB, 1>(p, x1, one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+              for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int f2 = 0; f2 < kFPW; ++f2)
+                  melall[c2][f2][r] = (c2 == c && f2 == ff) ? m1[0][r] : melall[c2][f2][r];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          float (&mel)[kFPW][NB] = melall[c];
 #pragma unroll
           for (int ff = 0; ff < kFPW; ++ff) {
             float lsum = 0.f, msum = 0.f;
@@ -487,8 +610,8 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 
 // ------------------------------------------------------------------------------------------
 // Stage A, "stem per wave pair" layout for the standard configuration (hop == n_fft/4, n_mels <= 128, aligned
-// input).  Waves 2s and 2s+1 own stem s: a wave runs the L and the R FFT of ONE frame side by side (even / odd
-// frames of a 16-frame batch), so
+// input).  Waves 2s and 2s+1 own stem s: a wave transforms the L and the R channel of ONE frame as one complex FFT
+// (frames_mel_cplx; even / odd frames of a 16-frame batch), so
 //   * per-channel and L/R cross moments come from the un-windowed samples the frame owns (no moment pass; consecutive
 //     frames of a wave overlap by half, the partner wave covers the rest: L1/L2 hits),
 //   * all 8 channels x 16 frames of log-mel land in one frame-major LDS tile and are flushed once per batch
@@ -498,14 +621,13 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 // ------------------------------------------------------------------------------------------
 template <int NFFT>
 __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) {
-  constexpr int NB = 2, NC = NFFT / 2, NOWN = NFFT / 512;
-  constexpr int SCR1 = NC + NC / 8, SCR = 2 * SCR1;
+  constexpr int NB = 2, NOWN = NFFT / 256;
+  constexpr int SCR = NFFT + NFFT / 8;
   constexpr float kLn2 = 0.69314718055994530942f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2* s_win = reinterpret_cast<float2*>(smem);
-  float2* s_tw = s_win + NC;
-  float2* s_post = s_tw + p.tw_count;
-  float2* s_scr = s_post + NC;                                    // [kWaves][SCR]
+  float* s_winf = reinterpret_cast<float*>(smem);                 // [NFFT]
+  float2* s_tw2 = reinterpret_cast<float2*>(s_winf + NFFT);       // [tw2_count]
+  float2* s_scr = s_tw2 + p.tw2_count;                            // [kWaves][SCR]
   float* s_melw = reinterpret_cast<float*>(s_scr + kWaves * SCR);
   float* s_tile = s_melw + ((p.nnz + 3) & ~3);                    // [kTF][8*M + 1]  log-mel, frame-major
   const int M = p.M, TS = 8 * M + 1;
@@ -516,10 +638,8 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
   const int f_begin = run * p.frames_per_run;
   const int f_end = min(p.F, f_begin + p.frames_per_run);
   {
-    const float2* gw = reinterpret_cast<const float2*>(p.window);
-    for (int i = tid; i < NC; i += kThreads) s_win[i] = gw[i];
-    for (int i = tid; i < p.tw_count; i += kThreads) s_tw[i] = p.tw[i];
-    for (int i = tid; i < NC; i += kThreads) s_post[i] = p.post[i];
+    for (int i = tid; i < NFFT; i += kThreads) s_winf[i] = p.window[i];
+    for (int i = tid; i < p.tw2_count; i += kThreads) s_tw2[i] = p.tw2[i];
     for (int i = tid; i < p.nnz; i += kThreads) s_melw[i] = p.melw[i];
   }
   int lb_band[NB], lb_start[NB];
@@ -545,15 +665,14 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
   __syncthreads();
 
   for (int fb = f_begin; fb < f_end; fb += kTF) {
-    // ---- phase A: every wave: 8 frames of its stem, L and R side by side
+    // ---- phase A: every wave: 8 frames of its stem, L and R as one complex FFT
 #pragma unroll 1
     for (int i = 0; i < kTF / 2; ++i) {
       const int fr = fb + 2 * i + half;
       if (fr >= f_end) break;  // wave-uniform
-      const int frame[2] = {fr, fr};
       float mel[2][NB];
-      float2 raw[2][NOWN];
-      frames_mel<NFFT, NB, 2, true>(p, xs, frame, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, mel, raw);
+      float2 raw[NOWN];        // (L, R) of the samples the frame owns
+      frames_mel_cplx<NFFT, NB, true>(p, xs[0], xs[1], fr, fr, lane, s_winf, s_tw2, s_melw, scr, lb_start, mel, raw);
       float* trow = s_tile + (fr - fb) * TS + 2 * stem * M;
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
@@ -567,22 +686,20 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
       }
       // waveform moments from the samples this frame owns
 #pragma unroll
-      for (int j = 0; j < NOWN; ++j)
-#pragma unroll
-        for (int comp = 0; comp < 2; ++comp) {
-          const int n = fr * p.hop + 2 * (lane + 64 * j) + comp;
-          const bool m = n < p.T;
-          const float L = m ? (comp ? raw[0][j].y : raw[0][j].x) : 0.f;
-          const float R = m ? (comp ? raw[1][j].y : raw[1][j].x) : 0.f;
-          const float dL = m ? L - pvL : 0.f, dR = m ? R - pvR : 0.f;
-          sqL = fmaf(L, L, sqL), sqR = fmaf(R, R, sqR);
-          pkL = fmaxf(pkL, fabsf(L)), pkR = fmaxf(pkR, fabsf(R));
-          dsL += dL, dsR += dR;
-          dqL = fmaf(dL, dL, dqL), dqR = fmaf(dR, dR, dqR);
-          cr = fmaf(dL, dR, cr);
-          mid = fmaf(L + R, L + R, mid);
-          side = fmaf(L - R, L - R, side);
-        }
+      for (int j = 0; j < NOWN; ++j) {
+        const int n = fr * p.hop + lane + 64 * j;
+        const bool m = n < p.T;
+        const float L = m ? raw[j].x : 0.f;
+        const float R = m ? raw[j].y : 0.f;
+        const float dL = m ? L - pvL : 0.f, dR = m ? R - pvR : 0.f;
+        sqL = fmaf(L, L, sqL), sqR = fmaf(R, R, sqR);
+        pkL = fmaxf(pkL, fabsf(L)), pkR = fmaxf(pkR, fabsf(R));
+        dsL += dL, dsR += dR;
+        dqL = fmaf(dL, dL, dqL), dqR = fmaf(dR, dR, dqR);
+        cr = fmaf(dL, dR, cr);
+        mid = fmaf(L + R, L + R, mid);
+        side = fmaf(L - R, L - R, side);
+      }
     }
     __syncthreads();
     // ---- phase B (all threads): flush the batch's log-mel, masking, mixture energy
@@ -874,6 +991,8 @@ struct mst_plan {
   int batches_per_run;
   float* d_window = nullptr;
   float2* d_tw = nullptr;
+  float2* d_tw2 = nullptr;
+  int tw2_count = 0;
   float2* d_post = nullptr;
   float* d_melw = nullptr;
   LaneBand* d_lanebands = nullptr;
@@ -883,7 +1002,7 @@ namespace {
 
 void add_pass_tw(std::vector<float2>& tw, int NC, int R, int NS) {
   if (NS == 1) return;
-  const int nbf = NC / R / 64;
+  const int nbf = NS <= 64 ? 1 : NC / R / 64;  // (lane + 64 u) % NS does not depend on u when NS divides 64
   for (int u = 0; u < nbf; ++u)
     for (int t = 1; t < R; ++t)
       for (int lane = 0; lane < 64; ++lane) {
@@ -971,6 +1090,11 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
   std::vector<float2> tw;
   for (auto pr : passes_of(p->nc)) add_pass_tw(tw, p->nc, pr.first, pr.second);
   p->tw_count = (int)tw.size();
+  std::vector<float2> tw2;
+  if (n_fft <= 1024)
+    for (auto pr : passes_of(n_fft)) add_pass_tw(tw2, n_fft, pr.first, pr.second);
+  p->tw2_count = (int)tw2.size();
+  if (tw2.empty()) tw2.push_back(make_float2(1.f, 0.f));
   std::vector<float2> post(p->nc);
   for (int q = 0; q < p->nc / 64; ++q)
     for (int lane = 0; lane < 64; ++lane) {
@@ -980,6 +1104,7 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
     }
   int rc;
   if ((rc = mst::upload(&p->d_window, window, (size_t)n_fft)) || (rc = mst::upload(&p->d_tw, tw.data(), tw.size())) ||
+      (rc = mst::upload(&p->d_tw2, tw2.data(), tw2.size())) ||
       (rc = mst::upload(&p->d_post, post.data(), post.size())) ||
       (rc = mst::upload(&p->d_melw, melw.data(), melw.size())) ||
       (rc = mst::upload(&p->d_lanebands, lbs.data(), lbs.size()))) {
@@ -992,7 +1117,7 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
 
 void mst_plan_destroy(mst_plan* p) {
   if (!p) return;
-  (void)hipFree(p->d_window), (void)hipFree(p->d_tw), (void)hipFree(p->d_post), (void)hipFree(p->d_melw),
+  (void)hipFree(p->d_window), (void)hipFree(p->d_tw), (void)hipFree(p->d_tw2), (void)hipFree(p->d_post), (void)hipFree(p->d_melw),
       (void)hipFree(p->d_lanebands);
   delete p;
 }
@@ -1028,7 +1153,7 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   for (int i = 0; i < 4; ++i) kp.stem[i] = stems4[i];
   kp.clip_stride = clip_stride;
   kp.logmel = logmel, kp.partials = reinterpret_cast<float*>(workspace);
-  kp.window = p->d_window, kp.tw = p->d_tw, kp.post = p->d_post, kp.melw = p->d_melw, kp.lanebands = p->d_lanebands;
+  kp.window = p->d_window, kp.tw = p->d_tw, kp.tw2 = p->d_tw2, kp.tw2_count = p->tw2_count, kp.post = p->d_post, kp.melw = p->d_melw, kp.lanebands = p->d_lanebands;
   kp.B = B, kp.T = T, kp.F = F, kp.M = p->n_mels, kp.hop = p->hop;
   kp.tw_count = p->tw_count, kp.nnz = p->nnz;
   for (int r = 0; r < 4; ++r) kp.glen[r] = p->glen[r], kp.goff[r] = p->goff[r];
@@ -1041,7 +1166,8 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   kp.vec4_ok = base16 && (T % 4 == 0) && (p->hop % 4 == 0) && (clip_stride % 4 == 0);
   const int nc = p->nc;
   const int nf = nf_of(p->n_fft);
-  size_t lds = (size_t)(nc + p->tw_count + nc + kWaves * nf * (nc + nc / 8)) * sizeof(float2) +
+  const bool pair = p->n_fft <= 1024;
+  size_t lds = (size_t)(nc + (pair ? p->tw2_count : p->tw_count + nc) + kWaves * nf * (nc + nc / 8)) * sizeof(float2) +
                (size_t)(((p->nnz + 3) & ~3) + 2 * 2 * p->n_mels * kTileStride) * sizeof(float);
   kp.tile_bufs = 2;
   if (lds > 160 * 1024) {  // fall back to a single output tile
@@ -1055,7 +1181,7 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   const int grid = B * kp.runs_per_clip;
   hipError_t e = hipErrorInvalidValue;
   // stem-per-wave-pair kernel for the standard configuration; the generic kernel covers everything else
-  const size_t lds_spw = (size_t)(nc + p->tw_count + nc + kWaves * 2 * (nc + nc / 8)) * sizeof(float2) +
+  const size_t lds_spw = (size_t)(nc + p->tw2_count + kWaves * (p->n_fft + p->n_fft / 8)) * sizeof(float2) +
                          (size_t)(((p->nnz + 3) & ~3) + kTF * (8 * p->n_mels + 1)) * sizeof(float);
   const bool spw = kp.vec_ok && kp.vec4_ok && p->hop * 4 == p->n_fft && p->n_mels <= 128 && p->nb == 2 &&
                    (p->n_fft == 512 || p->n_fft == 1024) && lds_spw <= 160 * 1024 && !getenv("MST_MELFEAT_GENERIC");
