@@ -75,6 +75,15 @@ int mst_melfeat_forward(const mst_plan* plan, const float* stems, int B, int T, 
 int mst_melfeat_forward_stems(const mst_plan* plan, const float* const stems4[4], long long clip_stride,
                               int B, int T, float* logmel, float* feats, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* Same two entry points for int16 PCM stems (the ingest format of SURVEY.md section 8 f2: pre-decoded PCM
+ * shards, half the PCIe and HBM bytes of fp32; the reference decodes `{stem}.mp3` to float at
+ * src/data.py:169-199).  Samples are converted in-kernel as float(s) * 2^-15 (exact), so the outputs are
+ * bit-identical to the fp32 entry points run on that conversion.  clip_stride is in samples.            */
+int mst_melfeat_forward_pcm16(const mst_plan* plan, const int16_t* stems, int B, int T, float* logmel,
+                              float* feats, void* workspace, size_t workspace_bytes, void* stream);
+int mst_melfeat_forward_stems_pcm16(const mst_plan* plan, const int16_t* const stems4[4], long long clip_stride,
+                                    int B, int T, float* logmel, float* feats, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Stage B: FiLM MLP + band-split Conv2D/BN/FiLM/ReLU/MaxPool x2 + attention pooling (eval).

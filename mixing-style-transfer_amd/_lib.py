@@ -62,6 +62,10 @@ SYMBOLS = {
                                       C.c_size_t, C.c_void_p]),
     "mst_melfeat_forward_stems": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_longlong, C.c_int, C.c_int,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_melfeat_forward_pcm16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_melfeat_forward_stems_pcm16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_longlong, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EncoderConfig), C.POINTER(EncoderWeights)]),
     "mst_encoder_destroy": (None, [C.c_void_p]),
     "mst_encoder_set_precision": (C.c_int, [C.c_void_p, C.c_int]),

@@ -58,7 +58,7 @@ struct LaneBand {  // one mel band owned by a lane: band id (-1 = none) and firs
 };
 
 struct KParams {
-  const float* stem[4];      // per-stem base pointers, each [B][2][T] with clip stride `clip_stride` floats
+  const void* stem[4];       // per-stem base pointers (float or int16 PCM), each [B][2][T], clip stride `clip_stride` samples
   long long clip_stride;     // 8*T for a packed [B][8][T] tensor, 2*T for four separate [B][2][T] tensors
   float* logmel;
   float* partials;
@@ -85,12 +85,36 @@ __device__ __forceinline__ float2 shfl2(float2 a, int src) {
   return make_float2(__shfl(a.x, src, 64), __shfl(a.y, src, 64));
 }
 
+// Sample type of the waveform in HBM: fp32, or int16 PCM (the ingest format: half the PCIe / HBM bytes; converted
+// with the exact scale 2^-15, so the result equals the fp32 path run on float(pcm) / 32768 bit for bit).
+template <typename ST> struct Smp;
+template <> struct Smp<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+  static __device__ __forceinline__ void ld4(const float* p, float (&x)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    x[0] = q.x, x[1] = q.y, x[2] = q.z, x[3] = q.w;
+  }
+};
+template <> struct Smp<short> {
+  static constexpr float kScale = 1.0f / 32768.0f;
+  static __device__ __forceinline__ float ld(const short* p) { return (float)*p * kScale; }
+  static __device__ __forceinline__ float2 ld2(const short* p) {
+    const short2 q = *reinterpret_cast<const short2*>(p);
+    return make_float2((float)q.x * kScale, (float)q.y * kScale);
+  }
+  static __device__ __forceinline__ void ld4(const short* p, float (&x)[4]) {
+    const short4 q = *reinterpret_cast<const short4*>(p);
+    x[0] = (float)q.x * kScale, x[1] = (float)q.y * kScale, x[2] = (float)q.z * kScale, x[3] = (float)q.w * kScale;
+  }
+};
+
 // mel power of NF frames of one channel, computed side by side (two independent FFT dependency chains per wave;
 // window, twiddles and mel weights are loaded once for both): returns this lane's NB band values per frame.
 // With hop == NFFT/4 the samples a frame "owns" for the waveform moments, [f*hop, (f+1)*hop), are elements
 // Q/2 .. Q/2 + Q/4 - 1 of every lane (float2 index lane + 64*q); RAW builds return them un-windowed in `raw`.
-template <int NFFT, int NB, int NF, bool RAW = false>
-__device__ __forceinline__ void frames_mel(const KParams& p, const float* const (&xchs)[NF], const int (&frame)[NF],
+template <int NFFT, int NB, int NF, bool RAW = false, typename ST = float>
+__device__ __forceinline__ void frames_mel(const KParams& p, const ST* const (&xchs)[NF], const int (&frame)[NF],
                                            int lane, const float2* s_win, const float2* s_tw, const float2* s_post,
                                            const float* s_melw, float2* scr, const int (&lb_start)[NB],
                                            float (&mel)[NF][NB], float2 (*raw)[NFFT / 512] = nullptr) {
@@ -118,7 +142,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* const 
         const float2 w = s_win[n];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          const float2 x = MST_ABLATE >= 4 ? make_float2(0.001f * n, 0.002f * lane) : reinterpret_cast<const float2*>(xchs[f] + s0[f])[n];
+          const float2 x = MST_ABLATE >= 4 ? make_float2(0.001f * n, 0.002f * lane) : Smp<ST>::ld2(xchs[f] + s0[f] + 2 * n);
           v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
           if constexpr (RAW) {
             const int q = u + t * NBF0;  // compile-time after unrolling
@@ -136,7 +160,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const float* const 
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           const int i0 = s0[f] + 2 * n;
-          const float2 x = make_float2(xchs[f][reflect_idx(i0, p.T)], xchs[f][reflect_idx(i0 + 1, p.T)]);
+          const float2 x = make_float2(Smp<ST>::ld(xchs[f] + reflect_idx(i0, p.T)), Smp<ST>::ld(xchs[f] + reflect_idx(i0 + 1, p.T)));
           v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
           if constexpr (RAW) {
             const int q = u + t * NBF0;
@@ -214,9 +238,9 @@ __device__ __forceinline__ unsigned wave_umax_uniform(unsigned m) {
 // frames' energies first, so each channel's error stays relative to its own level (the noise that remains is the
 // complex FFT's own rounding, which any fp32 FFT of that frame carries).  An all-zero frame returns exact zeros.
 // RAW: also return the un-windowed samples the frames own ([f*hop, (f+1)*hop): elements Q/2 .. Q/2+Q/4-1) as (a, b).
-template <int NFFT, int NB, bool RAW>
-__device__ __forceinline__ void frames_mel_cplx(const KParams& p, const float* __restrict__ xa,
-                                                const float* __restrict__ xb, int fA, int fB, int lane,
+template <int NFFT, int NB, bool RAW, typename ST>
+__device__ __forceinline__ void frames_mel_cplx(const KParams& p, const ST* __restrict__ xa,
+                                                const ST* __restrict__ xb, int fA, int fB, int lane,
                                                 const float* s_winf, const float2* s_tw2, const float* s_melw,
                                                 float2* scr, const int (&lb_start)[NB], float (&mel)[2][NB],
                                                 float2 (*raw)) {
@@ -237,8 +261,8 @@ __device__ __forceinline__ void frames_mel_cplx(const KParams& p, const float* _
       const float w = s_winf[n];
       float a, b;
       if (MST_ABLATE >= 4) a = 0.001f * n, b = 0.002f * lane;
-      else if (interior) a = xa[sA + n], b = xb[sB + n];
-      else a = xa[reflect_idx(sA + n, p.T)], b = xb[reflect_idx(sB + n, p.T)];
+      else if (interior) a = Smp<ST>::ld(xa + sA + n), b = Smp<ST>::ld(xb + sB + n);
+      else a = Smp<ST>::ld(xa + reflect_idx(sA + n, p.T)), b = Smp<ST>::ld(xb + reflect_idx(sB + n, p.T));
       const float aw = a * w, bw = b * w;
       ma = fmaxf(ma, fabsf(aw)), mb = fmaxf(mb, fabsf(bw));
       v[0][u * R0 + t] = make_float2(aw, bw);
@@ -296,7 +320,7 @@ __device__ __forceinline__ void frames_mel_cplx(const KParams& p, const float* _
   }
 }
 
-template <int NFFT, int NB>
+template <int NFFT, int NB, typename ST>
 __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
   constexpr int NC = NFFT / 2;
   constexpr int NF = nf_of(NFFT);            // FFTs a wave runs side by side
@@ -336,7 +360,9 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     lb_band[r] = q.band, lb_start[r] = q.start;
   }
 
-  auto chan = [&](int c) { return p.stem[c >> 1] + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T; };
+  auto chan = [&](int c) {
+    return static_cast<const ST*>(p.stem[c >> 1]) + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T;
+  };
   float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
   float* red = reinterpret_cast<float*>(s_scr);  // workgroup reduction buffer (aliases FFT scratch)
 
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     float piv[8], sq[8], pk[8], ds[8], dq[8], cr[4], mid[4], side[4], mix = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      piv[c] = n_own > 0 ? chan(c)[o_begin] : 0.f;
+      piv[c] = n_own > 0 ? Smp<ST>::ld(chan(c) + o_begin) : 0.f;
       sq[c] = pk[c] = ds[c] = dq[c] = 0.f;
     }
 #pragma unroll
@@ -363,13 +389,12 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
         const bool full = (i + 3 < n_own);
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float* src = chan(c) + o_begin + min(i, max(n_own - 1, 0));
+          const ST* src = chan(c) + o_begin + min(i, max(n_own - 1, 0));
           if (full && p.vec4_ok) {
-            const float4 q = *reinterpret_cast<const float4*>(src);
-            x[it][c][0] = q.x, x[it][c][1] = q.y, x[it][c][2] = q.z, x[it][c][3] = q.w;
+            Smp<ST>::ld4(src, x[it][c]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[it][c][e] = (i + e < n_own) ? src[e] : piv[c];
+            for (int e = 0; e < 4; ++e) x[it][c][e] = (i + e < n_own) ? Smp<ST>::ld(src + e) : piv[c];
           }
         }
       }
@@ -482,7 +507,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll 1
           for (int ff = 0; ff < kFPW; ++ff) {
             float m2[2][NB];
-            frames_mel_cplx<NFFT, NB, false>(p, chan(2 * s), chan(2 * s + 1), frame[ff], frame[ff], lane,
+            frames_mel_cplx<NFFT, NB, false, ST>(p, chan(2 * s), chan(2 * s + 1), frame[ff], frame[ff], lane,
                                              reinterpret_cast<const float*>(s_win), s_tw, s_melw, scr, lb_start, m2,
                                              nullptr);
 #pragma unroll
@@ -498,8 +523,8 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
             const int c = cf / kFPW, ff = cf % kFPW;
             const int one[1] = {frame[ff]};
             float m1[1][NB];
-            const float* const x1[1] = {chan(2 * s + c)};
-            frames_mel<NFFT, NB, 1>(p, x1, one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
+            const ST* const x1[1] = {chan(2 * s + c)};
+            frames_mel<NFFT, NB, 1, false, ST>(p, x1, one, lane, s_win, s_tw, s_post, s_melw, scr, lb_start, m1);
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
@@ -619,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 //   * the mixture energy comes from a short float4 pass over the batch's samples (just loaded: cache-resident).
 // Writes the same partial records as melfeat_kernel (same finalise kernel).
 // ------------------------------------------------------------------------------------------
-template <int NFFT>
+template <int NFFT, typename ST>
 __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) {
   constexpr int NB = 2, NOWN = NFFT / 256;
   constexpr int SCR = NFFT + NFFT / 8;
@@ -648,14 +673,16 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
     const LaneBand q = p.lanebands[r * 64 + lane];
     lb_band[r] = q.band, lb_start[r] = q.start;
   }
-  auto chan = [&](int c) { return p.stem[c >> 1] + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T; };
+  auto chan = [&](int c) {
+    return static_cast<const ST*>(p.stem[c >> 1]) + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T;
+  };
   float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
   const int stem = wave >> 1, half = wave & 1;
-  const float* const xs[2] = {chan(2 * stem), chan(2 * stem + 1)};
+  const ST* const xs[2] = {chan(2 * stem), chan(2 * stem + 1)};
   const int o_begin = f_begin * p.hop;
   const int o_end = (f_end == p.F) ? p.T : min(p.T, f_end * p.hop);
   const int o_piv = min(o_begin, p.T - 1);
-  const float pvL = xs[0][o_piv], pvR = xs[1][o_piv];
+  const float pvL = Smp<ST>::ld(xs[0] + o_piv), pvR = Smp<ST>::ld(xs[1] + o_piv);
   float2* scr = s_scr + wave * SCR;
 
   float acc_db[NB] = {0.f, 0.f}, acc_log = 0.f, acc_lin = 0.f;
@@ -672,7 +699,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
       if (fr >= f_end) break;  // wave-uniform
       float mel[2][NB];
       float2 raw[NOWN];        // (L, R) of the samples the frame owns
-      frames_mel_cplx<NFFT, NB, true>(p, xs[0], xs[1], fr, fr, lane, s_winf, s_tw2, s_melw, scr, lb_start, mel, raw);
+      frames_mel_cplx<NFFT, NB, true, ST>(p, xs[0], xs[1], fr, fr, lane, s_winf, s_tw2, s_melw, scr, lb_start, mel, raw);
       float* trow = s_tile + (fr - fb) * TS + 2 * stem * M;
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
@@ -732,13 +759,12 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
         float x[8][4];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const float* src = chan(c) + i;
+          const ST* src = chan(c) + i;
           if (i + 3 < b1) {
-            const float4 q = *reinterpret_cast<const float4*>(src);
-            x[c][0] = q.x, x[c][1] = q.y, x[c][2] = q.z, x[c][3] = q.w;
+            Smp<ST>::ld4(src, x[c]);
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[c][e] = (i + e < b1) ? src[e] : 0.f;
+            for (int e = 0; e < 4; ++e) x[c][e] = (i + e < b1) ? Smp<ST>::ld(src + e) : 0.f;
           }
         }
 #pragma unroll
@@ -796,7 +822,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
     float mk = 0.f;
     for (int w = 0; w < kWaves; ++w) mk += red2[w * 24 + 14 + s];
     q[S_MASK + s] = mk;
-    q[S_PIVOT + 2 * s] = chan(2 * s)[o_piv], q[S_PIVOT + 2 * s + 1] = chan(2 * s + 1)[o_piv];
+    q[S_PIVOT + 2 * s] = Smp<ST>::ld(chan(2 * s) + o_piv), q[S_PIVOT + 2 * s + 1] = Smp<ST>::ld(chan(2 * s + 1) + o_piv);
   }
   if (tid == 8) {
     float mx = 0.f;
@@ -963,16 +989,29 @@ __global__ __launch_bounds__(256) void melfeat_finalize_kernel(const FParams p) 
   }
 }
 
-template <int NFFT, int NB>
+template <int NFFT, int NB, typename ST>
 hipError_t launch_melfeat(const KParams& kp, int grid, size_t lds, hipStream_t st) {
   static size_t attr_lds = 0;  // raise the dynamic-LDS limit once per kernel (and again only if it grows)
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_kernel<NFFT, NB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_kernel<NFFT, NB, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((melfeat_kernel<NFFT, NB>), dim3(grid), dim3(kThreads), lds, st, kp);
+  hipLaunchKernelGGL((melfeat_kernel<NFFT, NB, ST>), dim3(grid), dim3(kThreads), lds, st, kp);
+  return hipGetLastError();
+}
+
+template <int NFFT, typename ST>
+hipError_t launch_melfeat_spw(const KParams& kp, int grid, size_t lds, hipStream_t st) {
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_spw_kernel<NFFT, ST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_lds = lds;
+  }
+  hipLaunchKernelGGL((melfeat_spw_kernel<NFFT, ST>), dim3(grid), dim3(kThreads), lds, st, kp);
   return hipGetLastError();
 }
 
@@ -1131,16 +1170,51 @@ size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
   return mst::align_up((size_t)B * runs_per_clip(p, F) * pstride_of(p) * sizeof(float), 256);
 }
 
+}  // extern "C"
+
+namespace {
+int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pcm16, long long clip_stride, int B, int T,
+                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream);
+}
+
+extern "C" {
+
 int mst_melfeat_forward(const mst_plan* p, const float* stems, int B, int T, float* logmel, float* feats,
                         void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(p && stems, "mst_melfeat_forward: NULL plan/stems");
-  const float* four[4] = {stems, stems + 2 * (size_t)T, stems + 4 * (size_t)T, stems + 6 * (size_t)T};
-  return mst_melfeat_forward_stems(p, four, (long long)8 * T, B, T, logmel, feats, workspace, workspace_bytes, stream);
+  const void* four[4] = {stems, stems + 2 * (size_t)T, stems + 4 * (size_t)T, stems + 6 * (size_t)T};
+  return melfeat_forward_impl(p, four, false, (long long)8 * T, B, T, logmel, feats, workspace, workspace_bytes, stream);
 }
 
 int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], long long clip_stride, int B, int T,
                               float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(p && stems4 && stems4[0] && stems4[1] && stems4[2] && stems4[3], "mst_melfeat_forward: NULL plan/stems");
+  MST_REQUIRE(p && stems4, "mst_melfeat_forward: NULL plan/stems");
+  const void* four[4] = {stems4[0], stems4[1], stems4[2], stems4[3]};
+  return melfeat_forward_impl(p, four, false, clip_stride, B, T, logmel, feats, workspace, workspace_bytes, stream);
+}
+
+int mst_melfeat_forward_pcm16(const mst_plan* p, const int16_t* stems, int B, int T, float* logmel, float* feats,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(p && stems, "mst_melfeat_forward_pcm16: NULL plan/stems");
+  const void* four[4] = {stems, stems + 2 * (size_t)T, stems + 4 * (size_t)T, stems + 6 * (size_t)T};
+  return melfeat_forward_impl(p, four, true, (long long)8 * T, B, T, logmel, feats, workspace, workspace_bytes, stream);
+}
+
+int mst_melfeat_forward_stems_pcm16(const mst_plan* p, const int16_t* const stems4[4], long long clip_stride, int B,
+                                    int T, float* logmel, float* feats, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  MST_REQUIRE(p && stems4, "mst_melfeat_forward_pcm16: NULL plan/stems");
+  const void* four[4] = {stems4[0], stems4[1], stems4[2], stems4[3]};
+  return melfeat_forward_impl(p, four, true, clip_stride, B, T, logmel, feats, workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pcm16, long long clip_stride, int B, int T,
+                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(p && stems4[0] && stems4[1] && stems4[2] && stems4[3], "mst_melfeat_forward: NULL plan/stems");
   MST_REQUIRE(clip_stride >= 2LL * T, "mst_melfeat_forward_stems: clip_stride %lld < 2*T", clip_stride);
   MST_REQUIRE(B > 0 && T > p->n_fft / 2, "mst_melfeat_forward: need B>0 and T > n_fft/2 (reflect pad); B=%d T=%d", B, T);
   MST_REQUIRE((long long)B * 8 * T < (1LL << 40), "mst_melfeat_forward: input too large");
@@ -1186,22 +1260,15 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   const bool spw = kp.vec_ok && kp.vec4_ok && p->hop * 4 == p->n_fft && p->n_mels <= 128 && p->nb == 2 &&
                    (p->n_fft == 512 || p->n_fft == 1024) && lds_spw <= 160 * 1024 && !getenv("MST_MELFEAT_GENERIC");
   if (spw) {
-    static size_t attr_spw[2] = {0, 0};
-    const int which = p->n_fft == 1024;
-    const void* fn = which ? reinterpret_cast<const void*>(melfeat_spw_kernel<1024>)
-                           : reinterpret_cast<const void*>(melfeat_spw_kernel<512>);
-    if (lds_spw > attr_spw[which]) {
-      e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_spw);
-      if (e != hipSuccess) return mst::fail(MST_EHIP, "melfeat_spw attribute failed: %s", hipGetErrorString(e));
-      attr_spw[which] = lds_spw;
-    }
-    if (which) hipLaunchKernelGGL((melfeat_spw_kernel<1024>), dim3(grid), dim3(kThreads), lds_spw, st, kp);
-    else hipLaunchKernelGGL((melfeat_spw_kernel<512>), dim3(grid), dim3(kThreads), lds_spw, st, kp);
-    e = hipGetLastError();
+    if (p->n_fft == 1024)
+      e = pcm16 ? launch_melfeat_spw<1024, short>(kp, grid, lds_spw, st) : launch_melfeat_spw<1024, float>(kp, grid, lds_spw, st);
+    else
+      e = pcm16 ? launch_melfeat_spw<512, short>(kp, grid, lds_spw, st) : launch_melfeat_spw<512, float>(kp, grid, lds_spw, st);
   } else {
-#define MST_CASE(NF)                                                       \
-  case NF:                                                                 \
-    e = (p->nb == 2) ? launch_melfeat<NF, 2>(kp, grid, lds, st) : launch_melfeat<NF, 4>(kp, grid, lds, st); \
+#define MST_CASE(NF)                                                                                          \
+  case NF:                                                                                                    \
+    if (pcm16) e = (p->nb == 2) ? launch_melfeat<NF, 2, short>(kp, grid, lds, st) : launch_melfeat<NF, 4, short>(kp, grid, lds, st); \
+    else e = (p->nb == 2) ? launch_melfeat<NF, 2, float>(kp, grid, lds, st) : launch_melfeat<NF, 4, float>(kp, grid, lds, st);       \
     break;
   switch (p->n_fft) {
     MST_CASE(512)
@@ -1222,4 +1289,4 @@ int mst_melfeat_forward_stems(const mst_plan* p, const float* const stems4[4], l
   return MST_OK;
 }
 
-}  // extern "C"
+}  // namespace

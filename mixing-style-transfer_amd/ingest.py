@@ -1,0 +1,190 @@
+"""Host ingest for the contrastive path: pre-decoded int16 PCM shards, crop, pinned-memory
+staging and asynchronous H2D copies that overlap the previous batch's kernels.
+
+Why: the reference keeps 4 x `{stem}.mp3` per track directory and decodes them in DataLoader workers to fp32
+(src/data.py:169-199); once stage A+B run at GPU speed the fp32 hand-over is PCIe-bound (14.1 MB per 10 s clip:
+63 GB/s => 4.4 k clips/s per GPU).  A shard stores the decoded track once as planar int16 (the precision the mp3 /
+wav sources carry), crops are contiguous byte ranges of a memory map, the batch crosses PCIe at half the bytes, and the
+stage-A kernels read int16 directly (`mst_melfeat_forward_pcm16`, exact 2^-15 scaling).
+
+Shard layout (little endian):  b"MSTPCM16" | u32 version=1 | u32 sample_rate | u64 n_samples | 8 x int16[n_samples]
+in the channel order vocals L,R, bass L,R, drums L,R, other L,R.
+"""
+import glob
+import os
+import struct
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from .mixing_utils import STEMS
+
+MAGIC = b"MSTPCM16"
+HEADER = struct.Struct("<8sIIQ")
+
+
+def float_to_pcm16(x: torch.Tensor) -> torch.Tensor:
+    """fp32 in [-1, 1) -> int16, round-to-nearest, saturating (the inverse of the kernels' s * 2^-15)."""
+    return torch.clamp(torch.round(x.float() * 32768.0), -32768, 32767).to(torch.int16)
+
+
+def write_pcm_shard(path, stems, sample_rate=44100):
+    """stems: {stem: (2, L) float|int16} or an (8, L) tensor -> one shard file."""
+    if isinstance(stems, dict):
+        stems = torch.cat([stems[s] for s in STEMS], dim=0)
+    if stems.dtype != torch.int16:
+        stems = float_to_pcm16(stems)
+    assert stems.dim() == 2 and stems.shape[0] == 8, "expected (8, L): 4 stems x stereo"
+    a = stems.contiguous().numpy()
+    with open(path, "wb") as f:
+        f.write(HEADER.pack(MAGIC, 1, int(sample_rate), a.shape[1]))
+        f.write(a.astype("<i2", copy=False).tobytes())
+
+
+def open_pcm_shard(path):
+    """-> (np.memmap int16 (8, L), sample_rate); nothing is read until a crop is sliced."""
+    with open(path, "rb") as f:
+        head = f.read(HEADER.size)
+    if len(head) != HEADER.size:
+        raise ValueError(f"{path}: truncated PCM shard header")
+    magic, version, sr, n = HEADER.unpack(head)
+    if magic != MAGIC or version != 1:
+        raise ValueError(f"{path}: not a PCM shard (magic {magic!r}, version {version})")
+    if os.path.getsize(path) != HEADER.size + 16 * n:
+        raise ValueError(f"{path}: size does not match header ({n} samples)")
+    return np.memmap(path, dtype="<i2", mode="r", offset=HEADER.size, shape=(8, n)), sr
+
+
+def convert_track_dir(track_dir, out_path, stem_loader, sample_rate=44100, stem_ext=".mp3"):
+    """One-off pre-decode of a reference track directory (`{stem}{ext}` x 4, src/data.py:180-199) into a shard."""
+    stems = {}
+    for name in STEMS:
+        p = os.path.join(track_dir, f"{name}{stem_ext}")
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"Stem file not found: {p}")
+        audio, sr = stem_loader(p)
+        if sr != sample_rate:
+            raise RuntimeError(f"{p}: sample rate {sr} != {sample_rate}; resample before sharding")
+        audio = audio.float()
+        audio = audio.repeat(2, 1) if audio.shape[0] == 1 else audio[:2]
+        stems[name] = audio
+    n = min(v.shape[1] for v in stems.values())
+    write_pcm_shard(out_path, {k: v[:, :n] for k, v in stems.items()}, sample_rate)
+
+
+class PcmShardDataset(Dataset):
+    """Same sampling contract as FMABaselineDataset (reference src/data.py:201-288: numpy global-RNG crop starts,
+    1 or 2 segments per song, zero-padded short clips) over `*.pcm16` shards; items carry int16 clips and no features
+    (they are computed per batch on the device).  Fork-safe: touches no GPU state."""
+
+    def __init__(self, shard_dir, clip_duration=10.0, sample_rate=44100, num_segments=2):
+        if not os.path.exists(shard_dir):
+            raise ValueError(f"Shard directory not found: {shard_dir}")
+        self.shards = sorted(glob.glob(os.path.join(shard_dir, "*.pcm16")))
+        self.track_dirs = self.shards
+        self.sr = sample_rate
+        self.clip_samples = int(clip_duration * sample_rate)
+        self.num_segments = num_segments
+
+    def __len__(self):
+        return len(self.shards)
+
+    def _crop_starts(self, audio_length):
+        C = self.clip_samples
+        if self.num_segments == 1:
+            m = audio_length - C
+            return [0 if m <= 0 else int(np.random.randint(0, m + 1))]
+        if self.num_segments == 2:
+            if audio_length < 2 * C:
+                return [0, 0]
+            s1 = int(np.random.randint(0, audio_length - 2 * C + 1))
+            s2 = int(np.random.randint(s1 + C, audio_length - C + 1))
+            return [s1, s2]
+        raise ValueError(f"num_segments={self.num_segments} is not supported. "
+                         f"Only num_segments=1 or num_segments=2 are implemented.")
+
+    def __getitem__(self, idx):
+        if self.num_segments not in (1, 2):
+            self._crop_starts(0)
+        mm, sr = open_pcm_shard(self.shards[idx])
+        if sr != self.sr:
+            raise RuntimeError(f"{self.shards[idx]}: sample rate {sr} != {self.sr}")
+        L, C = mm.shape[1], self.clip_samples
+        clips = []
+        for s in self._crop_starts(L):
+            seg = np.zeros((8, C), dtype=np.int16)
+            n = max(0, min(C, L - s))
+            seg[:, :n] = mm[:, s:s + n]
+            clips.append(torch.from_numpy(seg))
+        return clips, idx, self.shards[idx]
+
+
+def pcm_collate_fn(batch):
+    """[(clips, song_idx, path)] -> (stems (N, 8, C) int16, song_labels (N,) int64, paths [N]); the row order is the
+    reference collate's (src/data.py:291-328: segments of a song adjacent)."""
+    clips, labels, paths = [], [], []
+    for cl, idx, path in batch:
+        for c in cl:
+            clips.append(c)
+            labels.append(idx)
+            paths.append(path)
+    return torch.stack(clips, 0), torch.tensor(labels, dtype=torch.long), paths
+
+
+def stems_views(stems8: torch.Tensor):
+    """(N, 8, C) -> the reference's stems_dict of (N, 2, C) views (no copy)."""
+    return {s: stems8[:, 2 * i:2 * i + 2] for i, s in enumerate(STEMS)}
+
+
+class DeviceStager:
+    """Double-buffered pinned staging + async H2D on a private copy stream.
+
+        stager = DeviceStager((N, 8, C), torch.int16, device)
+        fut = stager.submit(batch0)                  # memcpy into pinned slot, enqueue H2D on the copy stream
+        for nxt in batches:
+            x = fut.get()                            # compute stream waits on the copy's event (no host sync)
+            fut = stager.submit(nxt)                 # next copy overlaps the kernels launched below
+            ... kernels on x ...
+    A slot is reused every `depth` submits; `get()` of the batch that used it before must have been consumed on the
+    compute stream by then -- the stager records that with an event and makes the copy stream wait on it."""
+
+    class _Future:
+        def __init__(self, dev_buf, ready, slot):
+            self._buf, self._ready, self._slot = dev_buf, ready, slot
+
+        def get(self, stream=None):
+            (stream or torch.cuda.current_stream(self._buf.device)).wait_event(self._ready)
+            return self._buf
+
+    def __init__(self, shape, dtype, device, depth=2):
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.host = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(depth)]
+        self.dev = [torch.empty(shape, dtype=dtype, device=self.device) for _ in range(depth)]
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.consumed = [None] * depth
+        self.k = 0
+
+    def submit(self, batch_cpu: torch.Tensor):
+        i = self.k % len(self.host)
+        self.k += 1
+        if batch_cpu.is_pinned():                   # e.g. DataLoader(pin_memory=True): copy straight from it
+            src = batch_cpu
+        else:
+            if self.k > len(self.host):
+                self.ready[i].synchronize()         # the slot's previous H2D has finished reading the pinned buffer
+            self.host[i].copy_(batch_cpu)           # pageable -> pinned (host memcpy)
+            src = self.host[i]
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[i] is not None:
+                self.copy_stream.wait_event(self.consumed[i])
+            self.dev[i].copy_(src, non_blocking=True)
+            self.ready[i].record(self.copy_stream)
+        return self._Future(self.dev[i], self.ready[i], i)
+
+    def release(self, fut, stream=None):
+        """Call after the last kernel that reads fut's buffer has been launched."""
+        ev = torch.cuda.Event()
+        ev.record(stream or torch.cuda.current_stream(self.device))
+        self.consumed[fut._slot] = ev

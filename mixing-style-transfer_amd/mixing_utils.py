@@ -78,9 +78,13 @@ class MelFeatPlan:
         if not parts[0].is_cuda:
             raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
         B, ch, T = parts[0].shape
-        ok = all(q.dtype == torch.float32 and tuple(q.shape) == (B, 2, T) and q.stride(2) == 1 and q.stride(1) == T
-                 and q.stride(0) == parts[0].stride(0) for q in parts) and (B == 1 or parts[0].stride(0) >= 2 * T)
+        dt = parts[0].dtype
+        ok = all(q.dtype == dt and tuple(q.shape) == (B, 2, T) and q.stride(2) == 1 and q.stride(1) == T
+                 and q.stride(0) == parts[0].stride(0) for q in parts) and (B == 1 or parts[0].stride(0) >= 2 * T) \
+            and dt in (torch.float32, torch.int16)
         if not ok:
+            if all(q.dtype == torch.int16 for q in parts):
+                return self.forward(torch.cat(parts, dim=1), want_logmel, want_feats)
             return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats)
         dev = parts[0].device
         F = self.frames(T)
@@ -89,27 +93,30 @@ class MelFeatPlan:
         ws, need = self._workspace(B, T, dev)
         ptrs = (C.c_void_p * 4)(*[q.data_ptr() for q in parts])
         stride = parts[0].stride(0) if B > 1 else 2 * T
+        L = _lib.lib()
+        fn = L.mst_melfeat_forward_stems_pcm16 if dt == torch.int16 else L.mst_melfeat_forward_stems
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mst_melfeat_forward_stems(self._h, ptrs, stride, B, T, _lib.dptr(logmel),
-                                                            _lib.dptr(feats), _lib.dptr(ws), need, _lib.stream_ptr(dev)),
-                       "mst_melfeat_forward_stems")
+            _lib.check(fn(self._h, ptrs, stride, B, T, _lib.dptr(logmel), _lib.dptr(feats), _lib.dptr(ws), need,
+                          _lib.stream_ptr(dev)), "mst_melfeat_forward_stems")
         return logmel, feats
 
     def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True):
-        """stems8 (B, 8, T) fp32 CUDA contiguous -> (logmel (B,8,M,F) | None, feats (B,Fd) | None)."""
+        """stems8 (B, 8, T) CUDA, fp32 or int16 PCM (value = s / 32768) -> (logmel (B,8,M,F) | None, feats (B,Fd) | None)."""
         if not stems8.is_cuda:
             raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
-        x = stems8.contiguous().float()
+        pcm16 = stems8.dtype == torch.int16
+        x = stems8.contiguous() if pcm16 else stems8.contiguous().float()
         B, ch, T = x.shape
         assert ch == 8, "expected 8 channels (4 stems x stereo)"
         F = self.frames(T)
         logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=x.device) if want_logmel else None
         feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=x.device) if want_feats else None
         ws, need = self._workspace(B, T, x.device)
+        L = _lib.lib()
+        fn = L.mst_melfeat_forward_pcm16 if pcm16 else L.mst_melfeat_forward
         with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().mst_melfeat_forward(self._h, _lib.dptr(x), B, T, _lib.dptr(logmel), _lib.dptr(feats),
-                                                      _lib.dptr(ws), need, _lib.stream_ptr(x.device)),
-                       "mst_melfeat_forward")
+            _lib.check(fn(self._h, _lib.dptr(x), B, T, _lib.dptr(logmel), _lib.dptr(feats), _lib.dptr(ws), need,
+                          _lib.stream_ptr(x.device)), "mst_melfeat_forward")
         return logmel, feats
 
 

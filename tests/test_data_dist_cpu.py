@@ -122,3 +122,67 @@ def test_sharded_gather_infonce_world2_gloo():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# PCM shard ingest
+# ---------------------------------------------------------------------------------------------------------------
+def _toy_track(L, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(8, L, generator=g) * 2 - 1) * 0.9
+
+
+def test_pcm_shard_roundtrip_and_errors(tmp_path):
+    from mst_amd import ingest
+    x = _toy_track(5000, 1)
+    p = str(tmp_path / "a.pcm16")
+    ingest.write_pcm_shard(p, x, 44100)
+    mm, sr = ingest.open_pcm_shard(p)
+    assert sr == 44100 and mm.shape == (8, 5000)
+    q = ingest.float_to_pcm16(x)
+    assert np.array_equal(np.asarray(mm), q.numpy())
+    assert (q.float() / 32768.0 - x).abs().max().item() <= 0.5 / 32768 + 1e-7
+    # saturation at full scale, dict input in reference stem order
+    d = {s: torch.full((2, 10), v) for s, v in zip(("vocals", "bass", "drums", "other"), (1.0, -1.0, 0.25, 0.0))}
+    ingest.write_pcm_shard(p, d)
+    mm, _ = ingest.open_pcm_shard(p)
+    assert mm[0, 0] == 32767 and mm[2, 0] == -32768 and mm[4, 0] == 8192 and mm[6, 0] == 0
+    with open(p, "r+b") as f:
+        f.write(b"XXXX")
+    with pytest.raises(ValueError):
+        ingest.open_pcm_shard(p)
+    with pytest.raises(ValueError):
+        ingest.PcmShardDataset(str(tmp_path / "missing"))
+
+
+def test_pcm_shard_dataset_matches_reference_sampling(tmp_path):
+    """Same numpy-RNG crop starts, zero padding and collate order as FMABaselineDataset (src/data.py:201-328)."""
+    from mst_amd import ingest
+    from oracle import dataset as odata
+    sr, dur = 1000, 1.0
+    lengths = [3500, 1500, 2000, 700]           # >2C, <2C, ==2C, <C
+    tracks = [_toy_track(L, 10 + i) for i, L in enumerate(lengths)]
+    for i, t in enumerate(tracks):
+        ingest.write_pcm_shard(str(tmp_path / f"t{i}.pcm16"), t, sr)
+    for nseg in (1, 2):
+        ds = ingest.PcmShardDataset(str(tmp_path), clip_duration=dur, sample_rate=sr, num_segments=nseg)
+        assert len(ds) == 4
+        np.random.seed(42)
+        items = [ds[i] for i in range(4)]
+        np.random.seed(42)
+        want = [odata.crop_starts(L, int(dur * sr), nseg) for L in lengths]
+        for (clips, idx, path), starts, t in zip(items, want, tracks):
+            assert len(clips) == nseg
+            q = ingest.float_to_pcm16(t)
+            for c, s in zip(clips, starts):
+                ref = torch.zeros(8, 1000, dtype=torch.int16)
+                n = max(0, min(1000, q.shape[1] - s))
+                ref[:, :n] = q[:, s:s + n]
+                assert torch.equal(c, ref)
+        stems, labels, paths = ingest.pcm_collate_fn(items)
+        assert stems.shape == (4 * nseg, 8, 1000) and stems.dtype == torch.int16
+        assert labels.tolist() == [i for i in range(4) for _ in range(nseg)]
+        v = ingest.stems_views(stems)
+        assert v["drums"].shape == (4 * nseg, 2, 1000) and v["drums"].data_ptr() == stems[:, 4:6].data_ptr()
+    with pytest.raises(ValueError):
+        ingest.PcmShardDataset(str(tmp_path), num_segments=3)[0]

@@ -187,3 +187,52 @@ def test_sub_methods_and_errors():
         ext.extract_all_features({k: v[:, :300] for k, v in d.items()})   # T <= n_fft/2: reflect pad impossible
     with pytest.raises(_lib.MstError):
         fe(n_fft=4096, hop_length=1024).plan()                             # unsupported FFT size
+
+
+@pytest.mark.parametrize("kw,T", [
+    (dict(), 88200),                                             # stem-per-wave-pair kernel
+    (dict(n_fft=2048, hop_length=512, n_mels=80), 66150),        # generic kernel, even/odd packed FFT
+    (dict(n_fft=1024, hop_length=256, n_mels=256), 44100),       # generic kernel, 4 band slots
+    (dict(n_fft=512, hop_length=128, n_mels=64), 30001),         # odd length: scalar loads
+])
+def test_pcm16_input_is_bit_identical_to_fp32_of_the_same_samples(kw, T):
+    """int16 PCM ingest: the kernels convert s * 2^-15 exactly, so features and log-mel must EQUAL the
+    fp32 entry point run on float(pcm) / 32768 -- packed (B,8,T) tensor and the collate-style dict of views."""
+    from mst_amd import ingest
+    x = torch.stack([cases.synth_clip(c, T) for c in (2, 4)], 0)
+    q = ingest.float_to_pcm16(x)
+    xf = q.float() / 32768.0
+    ext = fe(**kw)
+    f0, lm0 = run(xf, ext)
+    lm1, f1 = ext.plan().forward(q.cuda())
+    assert torch.equal(f1.cpu(), f0) and torch.equal(lm1.cpu(), lm0)
+    f2, lm2 = ext.features_and_logmel(ingest.stems_views(q.cuda()))
+    assert torch.equal(f2.cpu(), f0) and torch.equal(lm2.cpu(), lm0)
+    # and against the oracle on the dequantised samples
+    rf, rmel = ofeat.extract_all_features(xf, kw.get("sample_rate", 44100), kw.get("n_fft", 1024),
+                                          kw.get("hop_length", 256), kw.get("n_mels", 128), return_mel=True)
+    check_feats(f1.cpu(), rf)
+
+
+def test_device_stager_overlapped_h2d():
+    """Pinned double-buffered staging: every staged batch arrives intact while the previous one is being consumed."""
+    from mst_amd import ingest
+    ext = fe()
+    T, N = 44100, 3
+    batches = [ingest.float_to_pcm16(torch.stack([cases.synth_clip(10 * b + c, T) for c in range(N)], 0))
+               for b in range(5)]
+    st = ingest.DeviceStager((N, 8, T), torch.int16, "cuda")
+    fut = st.submit(batches[0])
+    outs = []
+    for b in range(5):
+        x = fut.get()
+        nxt = st.submit(batches[b + 1]) if b + 1 < 5 else None
+        lm, f = ext.plan().forward(x)
+        st.release(fut)
+        outs.append((f.clone(), x.clone()))
+        fut = nxt
+    torch.cuda.synchronize()
+    for b in range(5):
+        assert torch.equal(outs[b][1].cpu(), batches[b])
+        _, fr = ext.plan().forward(batches[b].cuda())
+        assert torch.equal(outs[b][0], fr)
