@@ -199,3 +199,92 @@ def shard_batch(stems_dict, features, song_labels, rank, world_size):
     lo, hi = rank * n // world_size, (rank + 1) * n // world_size
     return ({k: v[lo:hi] for k, v in stems_dict.items()}, None if features is None else features[lo:hi],
             song_labels[lo:hi])
+
+
+class StyleTransferDataset(Dataset):
+    """(input_stems, target_stems, target_features) with input and target from DIFFERENT songs -- reference
+    src/data.py:331-538, on the same feature kernels.  numpy global-RNG draws in the reference's order:
+    input crop `randint(0, L - C)` (only when L > C; upper bound exclusive, :481-482), target index `randint(0, len)`
+    redrawn while equal to idx (:516-519), target crop.  Short tracks are zero-padded (:471-477).
+    `compute_features` as in FMABaselineDataset: features need the device, so fork'd workers return None and the
+    batch's target features come from `MixingFeatureExtractor.extract_all_features(target_stems_dict)` on the GPU."""
+
+    def __init__(self, data_path=None, separated_path="/nas/FMA/fma_separated/", use_preseparated=True,
+                 scnet_separator=None, clip_duration=10.0, sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128,
+                 use_detailed_spectral=False, n_spectral_bins=32, compute_features="auto", stem_loader=None,
+                 stem_ext=".mp3", audio_loader=None, device=None):
+        self.data_path, self.separated_path, self.use_preseparated = data_path, separated_path, use_preseparated
+        self.scnet = scnet_separator
+        self.clip_duration, self.sr = clip_duration, sample_rate
+        self.n_fft, self.hop_length, self.n_mels = n_fft, hop_length, n_mels
+        self.clip_samples = int(clip_duration * sample_rate)
+        self.compute_features, self.device = compute_features, device
+        self.stem_loader = stem_loader or default_stem_loader
+        self.audio_loader = audio_loader or default_stem_loader
+        self.stem_ext = stem_ext
+        if use_preseparated:
+            if not os.path.exists(separated_path):
+                raise ValueError(f"Separated stems directory not found: {separated_path}")
+            self.track_dirs = [d for d in glob.glob(os.path.join(separated_path, "*")) if os.path.isdir(d)]
+        else:
+            self.audio_files = []
+            for ext in ("*.mp3", "*.wav", "*.flac"):
+                self.audio_files.extend(glob.glob(os.path.join(data_path, "**", ext), recursive=True))
+            if scnet_separator is None:
+                raise ValueError("scnet_separator required when use_preseparated=False")
+        self.feature_extractor = MixingFeatureExtractor(sample_rate, n_fft, hop_length, n_mels,
+                                                        use_detailed_spectral=use_detailed_spectral,
+                                                        n_spectral_bins=n_spectral_bins)
+
+    def __len__(self):
+        return len(self.track_dirs) if self.use_preseparated else len(self.audio_files)
+
+    def _load_full(self, idx):
+        if self.use_preseparated:
+            stems = {}
+            for name in STEMS:
+                path = os.path.join(self.track_dirs[idx], f"{name}{self.stem_ext}")
+                if not os.path.exists(path):
+                    raise FileNotFoundError(f"Missing stem: {path}")
+                audio, sr = self.stem_loader(path)
+                if sr != self.sr:
+                    raise RuntimeError(f"{path}: sample rate {sr} != {self.sr} (resampling needs torchaudio)")
+                audio = audio.float()
+                stems[name] = audio.repeat(2, 1) if audio.shape[0] == 1 else audio
+            return stems
+        audio, sr = self.audio_loader(self.audio_files[idx])
+        audio = audio.float()
+        return self.scnet.separate(audio.repeat(2, 1) if audio.shape[0] == 1 else audio)
+
+    def _random_crop_stems(self, stems_dict, duration_samples):
+        total = next(iter(stems_dict.values())).shape[1]
+        if total <= duration_samples:
+            return {k: torch.nn.functional.pad(v, (0, duration_samples - total)) for k, v in stems_dict.items()}
+        start = int(np.random.randint(0, total - duration_samples))
+        return {k: v[:, start:start + duration_samples] for k, v in stems_dict.items()}
+
+    def __getitem__(self, idx):
+        if len(self) < 2:
+            raise ValueError("StyleTransferDataset needs at least two songs (the target must differ from the input)")
+        input_stems = self._random_crop_stems(self._load_full(idx), self.clip_samples)
+        target_idx = int(np.random.randint(0, len(self)))
+        while target_idx == idx:
+            target_idx = int(np.random.randint(0, len(self)))
+        target_stems = self._random_crop_stems(self._load_full(target_idx), self.clip_samples)
+        mode = self.compute_features
+        if mode == "auto":
+            mode = torch.cuda.is_initialized() if torch.cuda.is_available() else False
+        feats = None
+        if mode:
+            dev = self.device or "cuda"
+            feats = self.feature_extractor.extract_all_features({k: v.to(dev) for k, v in target_stems.items()}).cpu()
+        return input_stems, target_stems, feats
+
+
+def style_transfer_collate_fn(batch):
+    """[(input_stems, target_stems, target_features)] -> (input {stem: (B,2,T)}, target {stem: (B,2,T)}, (B,F) | None)
+    reference src/data.py:541-578."""
+    inp = {s: torch.stack([b[0][s] for b in batch], 0) for s in STEMS}
+    tgt = {s: torch.stack([b[1][s] for b in batch], 0) for s in STEMS}
+    feats = None if any(b[2] is None for b in batch) else torch.stack([b[2] for b in batch], 0)
+    return inp, tgt, feats

@@ -186,3 +186,69 @@ def test_pcm_shard_dataset_matches_reference_sampling(tmp_path):
         assert v["drums"].shape == (4 * nseg, 2, 1000) and v["drums"].data_ptr() == stems[:, 4:6].data_ptr()
     with pytest.raises(ValueError):
         ingest.PcmShardDataset(str(tmp_path), num_segments=3)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Retrieval validation + style-transfer sampling
+# ---------------------------------------------------------------------------------------------------------------
+def test_retrieval_metrics_match_reference_loop():
+    from mst_amd import validation_utils as vu
+    from oracle import retrieval as oret
+    g = torch.Generator().manual_seed(3)
+    pool = torch.randn(40, 32, generator=g)
+    pool_idx = list(range(100, 140))
+    q_idx = [100 + i for i in (0, 5, 7, 11, 39, 20, 21)]
+    queries = torch.stack([pool[i - 100] + 0.9 * torch.randn(32, generator=g) for i in q_idx])
+    want = oret.evaluate_retrieval_accuracy(queries, pool, q_idx, pool_idx, (1, 3, 5))
+    got = vu.evaluate_retrieval_accuracy(queries, pool, q_idx, pool_idx, [1, 3, 5])
+    assert got == want and 0.0 < got["top_1_accuracy"] <= got["top_5_accuracy"] <= 1.0
+    i, s = vu.retrieve_top_k(queries[0], pool, k=5)
+    oi, os_ = oret.retrieve_top_k(queries[0], pool, k=5)
+    assert torch.equal(i, oi) and torch.allclose(s, os_) and (s[:-1] >= s[1:]).all()
+
+
+def test_style_transfer_dataset_sampling_and_collate(stem_dir):
+    from mst_amd.data import StyleTransferDataset, style_transfer_collate_fn
+    from oracle import retrieval as oret
+    ds = StyleTransferDataset(None, stem_dir, clip_duration=1.5, sample_rate=4000, stem_ext=".wav", compute_features=False)
+    assert len(ds) == 3 and ds.clip_samples == 6000
+    lengths = [5000 if d.endswith("short") else 9000 for d in ds.track_dirs]
+    np.random.seed(7)
+    items = [ds[i] for i in (0, 1, 2, 1)]
+    np.random.seed(7)
+    for (inp, tgt, feats), idx in zip(items, (0, 1, 2, 1)):
+        a, t, b = oret.style_transfer_draws(idx, lengths, 6000)
+        assert feats is None and t != idx
+        for stems, track, start in ((inp, idx, a), (tgt, t, b)):
+            full = ds._load_full(track)
+            for s in cases.STEMS:
+                assert stems[s].shape == (2, 6000)
+                if start is None:       # short track: zero padded, no RNG draw
+                    assert torch.equal(stems[s][:, :5000], full[s]) and not stems[s][:, 5000:].any()
+                else:
+                    assert torch.equal(stems[s], full[s][:, start:start + 6000])
+    i, t, f = style_transfer_collate_fn(items)
+    assert f is None and i["vocals"].shape == (4, 2, 6000) and torch.equal(t["other"][3], items[3][1]["other"])
+    with pytest.raises(ValueError):
+        StyleTransferDataset(None, stem_dir + "_missing")
+    with pytest.raises(ValueError):
+        StyleTransferDataset("x", stem_dir, use_preseparated=False)
+
+
+def test_load_stems_segment_dirs_and_shards(stem_dir, tmp_path):
+    from mst_amd import ingest, validation_utils as vu
+    from mst_amd.data import FMABaselineDataset
+    ds = make_ds(stem_dir)
+    d = [t for t in ds.track_dirs if t.endswith("short")][0]
+    seg = vu.load_stems_segment(d, 1.0, 0.5, 4000, stem_ext=".wav")
+    full = ds._load_stems(d)
+    for s in cases.STEMS:
+        assert seg[s].shape == (2, 2000) and np.array_equal(seg[s], full[s][:, 4000:6000].numpy()[:, :2000] if full[s].shape[1] >= 6000
+                                                           else np.pad(full[s][:, 4000:].numpy(), ((0, 0), (0, 1000))))
+    p = str(tmp_path / "short.pcm16")
+    ingest.write_pcm_shard(p, full, 4000)
+    seg2 = vu.load_stems_segment(p, 1.0, 0.5, 4000)
+    for s in cases.STEMS:   # wav fixtures are 16-bit: the shard reproduces them to within one LSB of the 32767/32768 scale
+        assert np.abs(seg2[s] - seg[s]).max() <= 1.5 / 32768
+    with pytest.raises(FileNotFoundError):
+        vu.load_stems_segment(str(tmp_path), 0.0, 1.0, 4000)

@@ -199,3 +199,57 @@ def test_song_a_real_music_end_to_end():
         model.conv1_precision = "fp32"
     close(emb.cpu(), g["embedding"], 2e-4)
     close(emb16.cpu(), g["embedding"], 2e-4)
+
+
+def test_retrieval_validation_on_hip_path(tmp_path):
+    """build_embedding_cache / compute_track_embedding (reference src/validation_utils.py:106-214) over
+    track directories and PCM shards, 1 s query segments -> embeddings equal the oracle's on the same samples; the
+    retrieval metric finds every track from a later, overlapping segment of itself."""
+    import wave
+    from mst_amd import ingest, validation_utils as vu
+    from mst_amd.mixing_utils import MixingFeatureExtractor
+    from oracle import features as ofeat
+    model, sd = build_model(cases.CFG_DEFAULT)
+    ext = MixingFeatureExtractor()
+    sr, L = 44100, 60000
+
+    class DS:
+        track_dirs = []
+    tracks = []
+    for t in range(5):
+        x = ingest.float_to_pcm16(cases.synth_clip(20 + t, L))        # int16 so that wav / shard / oracle agree exactly
+        tracks.append(x.float() / 32768.0)
+        if t < 3:                                                      # reference layout: 4 x {stem}.wav
+            d = tmp_path / f"track{t}"
+            d.mkdir()
+            for i, s in enumerate(cases.STEMS):
+                with wave.open(str(d / f"{s}.wav"), "wb") as w:
+                    w.setnchannels(2); w.setsampwidth(2); w.setframerate(sr)
+                    w.writeframes(x[2 * i:2 * i + 2].T.contiguous().numpy().astype("<i2").tobytes())
+            DS.track_dirs.append(str(d))
+        else:                                                          # PCM shard
+            p = str(tmp_path / f"track{t}.pcm16")
+            ingest.write_pcm_shard(p, x, sr)
+            DS.track_dirs.append(p)
+    DS.track_dirs.append(str(tmp_path / "missing_track"))              # reported and skipped, as in the reference
+    cache = vu.build_embedding_cache(DS, list(range(6)), model, ext, None, "cuda", query_duration=1.0,
+                                     batch_size=4, stem_ext=".wav")
+    assert cache["track_indices"] == [0, 1, 2, 3, 4] and cache["embeddings"].shape == (5, 768)
+    seg = torch.stack([t[:, :sr] for t in tracks], 0)
+    rf = ofeat.extract_all_features(seg)
+    want = oenc.encoder_forward(sd, seg, rf)
+    close(cache["embeddings"], want, 2e-4)
+    one = vu.compute_track_embedding(DS.track_dirs[1], 0.0, 1.0, model, ext, None, "cuda", stem_ext=".wav")
+    close(one, want[1], 2e-4)
+    st = vu.load_stems_segment(DS.track_dirs[4], 0.0, 1.0)
+    e4 = vu.compute_embedding(st, rf[4], model, "cuda")
+    close(e4, want[4], 2e-4)
+    # queries: a shifted window of every track against the pool of first seconds
+    q = torch.stack([vu.compute_track_embedding(DS.track_dirs[i], 0.05, 1.0, model, ext, None, "cuda", stem_ext=".wav")
+                     for i in range(5)])
+    m = vu.evaluate_retrieval_accuracy(q, cache["embeddings"], list(range(5)), cache["track_indices"], [1, 5])
+    from oracle import retrieval as oret
+    assert m == oret.evaluate_retrieval_accuracy(q, cache["embeddings"], list(range(5)), cache["track_indices"], (1, 5))
+    assert m["top_5_accuracy"] == 1.0     # (a random-init encoder does not separate the synthetic tracks at k=1)
+    vu.save_cache(cache, str(tmp_path / "c" / "cache.pt"))
+    assert torch.equal(vu.load_cache(str(tmp_path / "c" / "cache.pt"))["embeddings"], cache["embeddings"])
