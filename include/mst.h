@@ -179,6 +179,13 @@ size_t mst_infonce_workspace_bytes(int N, int D);
 int mst_infonce_forward(const float* emb, const int64_t* labels, int N, int D, int row0, int rows,
                         float temperature, float* out, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* Backward of the same sum (what autograd derives for src/loss.py:110-136):
+ * grad: dev [N][D], overwritten with  (*scale) * d( sum over valid local anchors of loss_i ) / d emb  for ALL N rows
+ *       (rows of other ranks receive the terms where they act as columns; the caller all-reduces and slices).
+ * scale: dev [1] (the upstream gradient, e.g. 1/#valid anchors) or NULL for 1.  Same workspace size as forward. */
+int mst_infonce_backward(const float* emb, const int64_t* labels, int N, int D, int row0, int rows,
+                         float temperature, const float* scale, float* grad, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

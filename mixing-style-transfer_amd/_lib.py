@@ -78,6 +78,8 @@ SYMBOLS = {
     "mst_infonce_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mst_infonce_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_infonce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

@@ -60,21 +60,51 @@ def info_nce_rows(all_emb, all_labels, row0, rows, temperature):
     return torch.where(keep, li, torch.zeros_like(li)).sum(), keep.sum()
 
 
-def info_nce_rows_hip(all_emb, all_labels, row0, rows, temperature):
-    """Same as info_nce_rows, in one libmst.so launch pair (`mst_infonce_forward`); forward only."""
-    import ctypes as C
+def _infonce_ws(N, D, device):
     from . import _lib
-    e = all_emb.detach().contiguous().float()
-    lab = all_labels.contiguous().to(torch.int64)
-    N, D = e.shape
-    L = _lib.lib()
-    need = L.mst_infonce_workspace_bytes(N, D)
-    ws = torch.empty(need, dtype=torch.uint8, device=e.device)
-    out = torch.empty(2, dtype=torch.float32, device=e.device)
-    with torch.cuda.device(e.device):
-        _lib.check(L.mst_infonce_forward(_lib.dptr(e), _lib.dptr(lab), N, D, row0, rows, float(temperature), _lib.dptr(out),
-                                         _lib.dptr(ws), need, _lib.stream_ptr(e.device)), "mst_infonce_forward")
-    return out[0], out[1]
+    need = _lib.lib().mst_infonce_workspace_bytes(N, D)
+    return torch.empty(need, dtype=torch.uint8, device=device), need
+
+
+class _InfoNCERowsHip(torch.autograd.Function):
+    """(sum of row losses, #valid rows) in libmst.so; backward = `mst_infonce_backward` (gradient for all N rows)."""
+
+    @staticmethod
+    def forward(ctx, all_emb, all_labels, row0, rows, temperature):
+        from . import _lib
+        e = all_emb.detach().contiguous().float()
+        lab = all_labels.contiguous().to(torch.int64)
+        N, D = e.shape
+        ws, need = _infonce_ws(N, D, e.device)
+        out = torch.empty(2, dtype=torch.float32, device=e.device)
+        with torch.cuda.device(e.device):
+            _lib.check(_lib.lib().mst_infonce_forward(_lib.dptr(e), _lib.dptr(lab), N, D, row0, rows, float(temperature),
+                                                      _lib.dptr(out), _lib.dptr(ws), need, _lib.stream_ptr(e.device)),
+                       "mst_infonce_forward")
+        ctx.save_for_backward(e, lab)
+        ctx.cfg = (row0, rows, float(temperature))
+        ctx.mark_non_differentiable(out[1])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_sum, _g_cnt):
+        from . import _lib
+        e, lab = ctx.saved_tensors
+        row0, rows, temperature = ctx.cfg
+        N, D = e.shape
+        ws, need = _infonce_ws(N, D, e.device)
+        grad = torch.empty_like(e)
+        scale = g_sum.detach().reshape(1).float().contiguous()
+        with torch.cuda.device(e.device):
+            _lib.check(_lib.lib().mst_infonce_backward(_lib.dptr(e), _lib.dptr(lab), N, D, row0, rows, temperature,
+                                                       _lib.dptr(scale), _lib.dptr(grad), _lib.dptr(ws), need,
+                                                       _lib.stream_ptr(e.device)), "mst_infonce_backward")
+        return grad, None, None, None, None
+
+
+def info_nce_rows_hip(all_emb, all_labels, row0, rows, temperature):
+    """Same as info_nce_rows, in libmst.so (`mst_infonce_forward` / `mst_infonce_backward`); differentiable."""
+    return _InfoNCERowsHip.apply(all_emb, all_labels, row0, rows, temperature)
 
 
 class InfoNCELoss(nn.Module):
@@ -89,7 +119,7 @@ class InfoNCELoss(nn.Module):
         if self.gather:
             import torch.distributed as dist
             all_e, all_l, row0 = gather_embeddings(embeddings, song_labels)
-            rows_fn = info_nce_rows if (all_e.requires_grad or not all_e.is_cuda) else info_nce_rows_hip
+            rows_fn = info_nce_rows_hip if all_e.is_cuda else info_nce_rows
             s, c = rows_fn(all_e, all_l, row0, embeddings.shape[0], self.temperature)
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 sc = torch.stack([s.detach(), c.to(s.dtype)])
@@ -101,7 +131,7 @@ class InfoNCELoss(nn.Module):
                 share = s / sc[1]
                 return share + (sc[0] / sc[1] - share).detach() if s.requires_grad else sc[0] / sc[1]
         else:
-            rows_fn = info_nce_rows if (embeddings.requires_grad or not embeddings.is_cuda) else info_nce_rows_hip
+            rows_fn = info_nce_rows_hip if embeddings.is_cuda else info_nce_rows
             s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
         if c.item() == 0:
             raise RuntimeError(

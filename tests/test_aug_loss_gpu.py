@@ -117,3 +117,31 @@ def test_infonce_kernel_vs_golden_and_oracle():
         close(s_all.item(), st.item(), rtol=1e-5)
     with pytest.raises(RuntimeError):
         InfoNCELoss(0.1)(torch.randn(4, 8).cuda(), torch.arange(4).cuda())
+
+
+def test_infonce_backward_vs_autograd_of_the_oracle():
+    """`mst_infonce_backward` == torch autograd through the oracle's loss (float64), whole batch and
+    row-sharded (each shard yields gradients for ALL rows; their sum is the whole-batch gradient)."""
+    from mst_amd.loss import InfoNCELoss, info_nce_rows_hip
+    gen = torch.Generator().manual_seed(11)
+    for n, d, nsong in ((48, 768, 24), (12, 16, 4), (9, 32, 5)):       # last: songs 4 has a single clip -> no positive
+        e = torch.randn(n, d, generator=gen) * (1.0 + torch.rand(n, 1, generator=gen))
+        lab = torch.arange(n) % nsong
+        ed = e.double().requires_grad_(True)
+        lo = oloss.info_nce(ed, lab, 0.1)
+        lo.backward()
+        ec = e.cuda().requires_grad_(True)
+        lg = InfoNCELoss(0.1)(ec, lab.cuda())
+        lg.backward()
+        close(lg.item(), lo.item(), rtol=1e-5, atol=1e-6)
+        ref = ed.grad.float()
+        assert (ec.grad.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-7
+        # sharded rows
+        nvalid = int(sum((lab == lab[i]).sum() > 1 for i in range(n)))
+        tot = torch.zeros_like(ref)
+        for r0, rows in ((0, n // 3), (n // 3, n - n // 3)):
+            es = e.cuda().requires_grad_(True)
+            s, c = info_nce_rows_hip(es, lab.cuda(), r0, rows, 0.1)
+            (s / nvalid).backward()
+            tot += es.grad.cpu()
+        assert (tot - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-7
