@@ -1,0 +1,24 @@
+#!/bin/bash
+# SQ counter passes over the stage-A kernel alone (scripts/probe_melfeat3.py: 33 launches of 72 clips); run through gpurun.
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+TAG=${1:-sa}
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_IFETCH"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/prof_${TAG}_$i -- python3 $R/scripts/probe_melfeat3.py > $R/gpurun_out/prof_${TAG}_$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<PY
+import csv, glob, collections
+for d in sorted(glob.glob("$R/gpurun_out/prof_${TAG}_*/")):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        for row in csv.DictReader(open(f)):
+            if "melfeat_spw" in row["Kernel_Name"] or "melfeat_kernel" in row["Kernel_Name"]:
+                a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+        for k, (v, n) in acc.items():
+            print(f"{k:28s} {v / n:16.0f} per launch ({n} launches)")
+PY
