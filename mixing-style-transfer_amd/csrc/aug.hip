@@ -3,7 +3,8 @@
 // :435-447, apply_bandwidth_limit :449-456, apply_reverb :458-479.  All random decisions (coins, gain, cutoff,
 // impulse response) are drawn by the host in the reference's order and arrive in `mst_aug_clip` / `reverb_ir`.
 //
-//   aug_chain_kernel   per (clip, channel): x*gain -> biquad (tilt) -> compressor -> 2 biquads (low-pass).
+//   aug_tilt_zs / aug_scan<0> / aug_tilt_resp / aug_scan<1> / aug_bw_resp: x*gain -> biquad (tilt) -> compressor
+//                      -> 1-2 biquads (low-pass), thread per 512-sample chunk, float64 block-parallel IIR.
 //                      scipy.signal.sosfilt is a sequential fp64 DF2T recurrence; here the channel is cut into
 //                      512-sample chunks and solved as a block-parallel state-space scan in fp64:
 //                      (1) zero-state response of every chunk in parallel, (2) serial carry of the chunk-boundary
@@ -40,112 +41,221 @@ __device__ __forceinline__ float compress_f32(float x) {  // mixing_utils.py:435
   return sgn * powf(10.0f, db / 20.0f);
 }
 
-// one DF2T biquad step, scipy.signal._sosfilt order; c = {b0,b1,b2,a0,a1,a2}
-__device__ __forceinline__ double biquad(const double* c, double* s, double x) {
-  const double y = c[0] * x + s[0];
-  s[0] = c[1] * x - c[4] * y + s[1];
-  s[1] = c[2] * x - c[5] * y;
+// ---- block-parallel IIR: chunk c of a stream = samples [c*kLc, (c+1)*kLc).
+//   zero-state pass (thread per chunk)  ->  z_c = final filter state of the chunk started from rest
+//   scan (one wave per stream)          ->  start state of every chunk: s_{c+1} = A^kLc s_c + z_c
+//   response pass (thread per chunk)    ->  true output from the start state
+// The chain is: x*gain -> [tilt biquad] -> [compressor] -> store -> [1-2 low-pass biquads]; the tilt response pass
+// also runs the low-pass zero-state pass on the values it has just produced (one read of the waveform less).
+// Every sample goes through exactly the reference's arithmetic (float64 DF2T, scipy sosfilt order, `.float()` after
+// each filter, mixing_utils.py:421-456); only the chunk start states are obtained differently.
+struct Coef {   // one biquad of an sos row {b0,b1,b2,a0,a1,a2}: b0, b1, b2, a1, a2
+  double b0, b1, b2, a1, a2;
+};
+__device__ __forceinline__ Coef coef_of(const double* c) { return Coef{c[0], c[1], c[2], c[4], c[5]}; }
+__device__ __forceinline__ double biquad_step(const Coef& c, double& s0, double& s1, double x) {
+  const double y = c.b0 * x + s0;
+  s0 = c.b1 * x - c.a1 * y + s1;
+  s1 = c.b2 * x - c.a2 * y;
   return y;
 }
 
-template <int NS>
-__device__ void run_filter(float* x, int T, int nchunk, double* st, const double* sos, float gain, bool compress,
-                           double* M /* shared [4*4] */) {
-  constexpr int D = 2 * NS;
-  const int tid = threadIdx.x, nth = blockDim.x;
-  // (1) zero-state final state of every chunk
-  for (int c = tid; c < nchunk; c += nth) {
-    double s[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) s[i] = 0.0;
-    const int n0 = c * kLc, n1 = min(T, n0 + kLc);
+// walk one chunk 4 samples at a time (16-byte loads, next group prefetched) or sample by sample when the chunk is
+// ragged / unaligned; f(value) returns the value to store, STORE selects whether it is written back
+template <bool STORE, typename F>
+__device__ __forceinline__ void walk_chunk(float* x, int n0, int n1, F&& f) {
+  if (n1 - n0 == kLc && (reinterpret_cast<uintptr_t>(x + n0) & 15) == 0) {
+    float4 cur = *reinterpret_cast<const float4*>(x + n0);
+#pragma unroll 2
+    for (int i = 0; i < kLc; i += 4) {
+      const float4 nxt = *reinterpret_cast<const float4*>(x + n0 + min(i + 4, kLc - 4));
+      float4 o;
+      o.x = f(cur.x), o.y = f(cur.y), o.z = f(cur.z), o.w = f(cur.w);
+      if (STORE) *reinterpret_cast<float4*>(x + n0 + i) = o;
+      cur = nxt;
+    }
+  } else {
     for (int n = n0; n < n1; ++n) {
-      double v = (double)(x[n] * gain);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) v = biquad(sos + 6 * k, s + 2 * k, v);
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i) st[(size_t)c * 4 + i] = s[i];
-  }
-  // A^kLc, one column per thread: homogeneous response to a unit initial state
-  if (tid < D) {
-    double s[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) s[i] = (i == tid) ? 1.0 : 0.0;
-    for (int n = 0; n < kLc; ++n) {
-      double v = 0.0;
-#pragma unroll
-      for (int k = 0; k < NS; ++k) v = biquad(sos + 6 * k, s + 2 * k, v);
-    }
-#pragma unroll
-    for (int i = 0; i < D; ++i) M[i * 4 + tid] = s[i];
-  }
-  __syncthreads();
-  // (2) serial carry: st[c] <- state at the START of chunk c
-  if (tid == 0) {
-    double carry[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) carry[i] = 0.0;
-    for (int c = 0; c < nchunk; ++c) {
-      double zs[D], nx[D];
-#pragma unroll
-      for (int i = 0; i < D; ++i) zs[i] = st[(size_t)c * 4 + i], st[(size_t)c * 4 + i] = carry[i];
-#pragma unroll
-      for (int i = 0; i < D; ++i) {
-        double a = zs[i];
-#pragma unroll
-        for (int j = 0; j < D; ++j) a += M[i * 4 + j] * carry[j];
-        nx[i] = a;
-      }
-#pragma unroll
-      for (int i = 0; i < D; ++i) carry[i] = nx[i];
+      const float o = f(x[n]);
+      if (STORE) x[n] = o;
     }
   }
-  __syncthreads();
-  // (3) true response, rounded to fp32 where the reference does `.float()`
-  for (int c = tid; c < nchunk; c += nth) {
-    double s[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) s[i] = st[(size_t)c * 4 + i];
-    const int n0 = c * kLc, n1 = min(T, n0 + kLc);
-    for (int n = n0; n < n1; ++n) {
-      double v = (double)(x[n] * gain);
-#pragma unroll
-      for (int k = 0; k < NS; ++k) v = biquad(sos + 6 * k, s + 2 * k, v);
-      float y = (float)v;
-      if (compress) y = compress_f32(y);
-      x[n] = y;
-    }
-  }
-  __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void aug_chain_kernel(const ChainParams p) {
-  __shared__ double M[16];
-  __shared__ double sos[18];
-  const int b = blockIdx.x >> 3, ch = blockIdx.x & 7;
-  const mst_aug_stem& d = p.dec[b].stem[ch >> 1];
-  const bool has_g = d.gain != 1.0f, has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
-  if (!(has_g || has_t || has_c || has_b)) return;
-  float* x = p.stems + ((size_t)b * 8 + ch) * p.T;
-  double* st = p.states + ((size_t)b * 8 + ch) * p.nchunk * 4;
-  if (threadIdx.x < 6) sos[threadIdx.x] = d.tilt_sos[threadIdx.x];
-  if (threadIdx.x < 12) sos[6 + threadIdx.x] = d.bw_sos[threadIdx.x];
+// grid (ceil(nchunk/256), B*8): zero-state pass of the tilt biquad on x*gain
+__global__ __launch_bounds__(256) void aug_tilt_zs_kernel(const ChainParams p) {
+  const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
+  if (d.tilt == 0 || c >= p.nchunk) return;
+  float* x = p.stems + (size_t)stream * p.T;
+  const Coef k = coef_of(d.tilt_sos);
+  const float gain = d.gain;
+  double s0 = 0.0, s1 = 0.0;
+  walk_chunk<false>(x, c * kLc, min(p.T, (c + 1) * kLc), [&](float v) {
+    (void)biquad_step(k, s0, s1, (double)(v * gain));
+    return 0.f;
+  });
+  double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
+  st[0] = s0, st[1] = s1;
+}
+
+// grid (B*8), one wave: chunk start states from the zero-state finals.  WHICH 0: tilt (1 section), 1: low-pass (1-2).
+// Two levels: every lane folds its G = ceil(nchunk/64) consecutive chunks, lane 0 chains the 64 groups with M^G, every
+// lane then replays its chunks from its group's start state (serial depth 2G + 64 instead of nchunk).
+template <int WHICH>
+__global__ __launch_bounds__(64) void aug_scan_kernel(const ChainParams p) {
+  __shared__ double Msh[16], MGsh[16], agg[64 * 4], cin[64 * 4];
+  const int stream = blockIdx.x, lane = threadIdx.x;
+  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
+  const int NS = WHICH == 0 ? (d.tilt != 0 ? 1 : 0) : d.bw_sections;
+  if (NS == 0) return;   // block-uniform
+  const int D = 2 * NS;
+  const double* sos = WHICH == 0 ? d.tilt_sos : d.bw_sos;
+  double* st = p.states + (size_t)stream * p.nchunk * 4;
+  if (lane < 16) Msh[lane] = 0.0;
   __syncthreads();
-  if (has_t) {
-    run_filter<1>(x, p.T, p.nchunk, st, sos, d.gain, has_c, M);
-  } else if (has_g || has_c) {
-    for (int n = threadIdx.x; n < p.T; n += blockDim.x) {
-      float y = x[n] * d.gain;
-      if (has_c) y = compress_f32(y);
-      x[n] = y;
+  // M = A^kLc, one column per lane: homogeneous response to a unit initial state
+  if (lane < D) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 4; ++i) s[i] = (i == lane) ? 1.0 : 0.0;
+    const Coef k0 = coef_of(sos), k1 = coef_of(sos + (NS > 1 ? 6 : 0));
+    for (int n = 0; n < kLc; ++n) {
+      double v = biquad_step(k0, s[0], s[1], 0.0);
+      if (NS > 1) v = biquad_step(k1, s[2], s[3], v);
     }
-    __syncthreads();
+    for (int i = 0; i < D; ++i) Msh[i * 4 + lane] = s[i];
   }
-  if (has_b) {
-    if (d.bw_sections == 1) run_filter<1>(x, p.T, p.nchunk, st, sos + 6, 1.0f, false, M);
-    else run_filter<2>(x, p.T, p.nchunk, st, sos + 6, 1.0f, false, M);
+  __syncthreads();
+  double M[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) M[i][j] = Msh[i * 4 + j];   // zero outside the D x D block
+  const int G = (p.nchunk + 63) / 64;
+  const int c0 = min(p.nchunk, lane * G), c1 = min(p.nchunk, c0 + G);
+  auto step = [&](double (&a)[4], int c) {   // a <- M a + z_c
+    double nx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      double t = i < D ? st[(size_t)c * 4 + i] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t += M[i][j] * a[j];
+      nx[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = nx[i];
+  };
+  // (1) fold this lane's chunks from rest; lane 0 also forms M^G
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c = c0; c < c1; ++c) step(a, c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) agg[lane * 4 + i] = a[i];
+  if (lane == 0) {
+    double P[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) P[i][j] = M[i][j];
+    for (int g = 1; g < G; ++g) {
+      double Q[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double t = 0.0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) t += M[i][k] * P[k][j];
+          Q[i][j] = t;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[i][j] = Q[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) MGsh[i * 4 + j] = P[i][j];
   }
+  __syncthreads();
+  // (2) chain the 64 groups
+  if (lane == 0) {
+    double cr[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < 64; ++g) {
+      double nx[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        cin[g * 4 + i] = cr[i];
+        double t = agg[g * 4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += MGsh[i * 4 + j] * cr[j];
+        nx[i] = t;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cr[i] = nx[i];
+    }
+  }
+  __syncthreads();
+  // (3) start state of every chunk of the group (overwrites z_c)
+  double sv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sv[i] = cin[lane * 4 + i];
+  for (int c = c0; c < c1; ++c) {
+    double keep[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) keep[i] = sv[i];
+    step(sv, c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < D) st[(size_t)c * 4 + i] = keep[i];
+  }
+}
+
+// grid (ceil(nchunk/256), B*8): gain -> tilt response -> compressor -> store, then the low-pass zero-state pass on
+// the stored values
+__global__ __launch_bounds__(256) void aug_tilt_resp_kernel(const ChainParams p) {
+  const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
+  const bool has_g = d.gain != 1.0f, has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
+  if (!(has_g || has_t || has_c || has_b) || c >= p.nchunk) return;
+  float* x = p.stems + (size_t)stream * p.T;
+  double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
+  const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
+  double t0 = has_t ? st[0] : 0.0, t1 = has_t ? st[1] : 0.0;
+  double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  const float gain = d.gain;
+  const bool two = d.bw_sections > 1;
+  auto body = [&](float v) {
+    float y = v * gain;
+    if (has_t) y = (float)biquad_step(kt, t0, t1, (double)y);
+    if (has_c) y = compress_f32(y);
+    if (has_b) {
+      const double w = biquad_step(kb0, b0, b1, (double)y);
+      if (two) (void)biquad_step(kb1, b2, b3, w);
+    }
+    return y;
+  };
+  const int n0 = c * kLc, n1 = min(p.T, n0 + kLc);
+  if (has_g || has_t || has_c) walk_chunk<true>(x, n0, n1, body);
+  else walk_chunk<false>(x, n0, n1, body);
+  if (has_b) st[0] = b0, st[1] = b1, st[2] = b2, st[3] = b3;
+}
+
+// grid (ceil(nchunk/256), B*8): low-pass response from the scanned start states
+__global__ __launch_bounds__(256) void aug_bw_resp_kernel(const ChainParams p) {
+  const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
+  if (d.bw_sections <= 0 || c >= p.nchunk) return;
+  float* x = p.stems + (size_t)stream * p.T;
+  const double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
+  const Coef kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
+  const bool two = d.bw_sections > 1;
+  double b0 = st[0], b1 = st[1], b2 = two ? st[2] : 0.0, b3 = two ? st[3] : 0.0;
+  walk_chunk<true>(x, c * kLc, min(p.T, (c + 1) * kLc), [&](float v) {
+    double w = biquad_step(kb0, b0, b1, (double)v);
+    if (two) w = biquad_step(kb1, b2, b3, w);
+    return (float)w;
+  });
 }
 
 // mean(stem^2) over (2, T) per stem  ->  redistribution weights E_s / (sum_s E_s + 1e-8)   (:410-416)
@@ -366,7 +476,20 @@ int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inou
   mst_aug_clip* ddec = reinterpret_cast<mst_aug_clip*>(ws + L.dec);
   MST_HIP_CHECK(hipMemcpyAsync(ddec, decisions, (size_t)B * sizeof(mst_aug_clip), hipMemcpyHostToDevice, st));
   ChainParams cp{stems_inout, ddec, reinterpret_cast<double*>(ws + L.states), T, L.nchunk};
-  hipLaunchKernelGGL(aug_chain_kernel, dim3(B * 8), dim3(256), 0, st, cp);
+  bool any_tilt = false, any_bw = false;
+  for (int b = 0; b < B; ++b)
+    for (int s = 0; s < 4; ++s)
+      any_tilt = any_tilt || decisions[b].stem[s].tilt != 0, any_bw = any_bw || decisions[b].stem[s].bw_sections > 0;
+  const dim3 cgrid((L.nchunk + 255) / 256, B * 8);
+  if (any_tilt) {
+    hipLaunchKernelGGL(aug_tilt_zs_kernel, cgrid, dim3(256), 0, st, cp);
+    hipLaunchKernelGGL((aug_scan_kernel<0>), dim3(B * 8), dim3(64), 0, st, cp);
+  }
+  hipLaunchKernelGGL(aug_tilt_resp_kernel, cgrid, dim3(256), 0, st, cp);
+  if (any_bw) {
+    hipLaunchKernelGGL((aug_scan_kernel<1>), dim3(B * 8), dim3(64), 0, st, cp);
+    hipLaunchKernelGGL(aug_bw_resp_kernel, cgrid, dim3(256), 0, st, cp);
+  }
   MST_HIP_CHECK(hipGetLastError());
   if (any_rev) {
     float* prop = reinterpret_cast<float*>(ws + L.prop);
