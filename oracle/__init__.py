@@ -15,4 +15,7 @@ Pinning (see DESIGN.md "Oracle"):
     algorithm -> "pinned to algorithm", equality with a real torchaudio unverified.
   * SCNet separation and src/data.py: not importable (un-vendored submodule)
     -> dataset crop/collate logic restated from source, parity unpinned.
+  * retrieval metric / style-transfer sampling order (oracle/retrieval.py): restated
+    from src/validation_utils.py:217-282 and src/data.py:467-519; the reference holds
+    no fixtures for them and validation_utils.py needs librosa -> parity unpinned.
 """
