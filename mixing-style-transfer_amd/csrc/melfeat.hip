@@ -1060,8 +1060,20 @@ std::vector<std::pair<int, int>> passes_of(int NC) {
   return {};
 }
 
-int runs_per_clip(const mst_plan* p, int F) {
-  const int fpr = p->batches_per_run * kTF;
+// Frames per workgroup ("run").  Every workgroup costs about (frames + 2) frame-times and the device executes them in
+// rounds of one workgroup per CU; with 32 runs per clip any batch that is a multiple of 8 clips fills whole rounds of
+// the 256 CUs: 72 clips of 1723 frames -> 54-frame runs, 2304 workgroups = 9.0 rounds (486 frame-times per CU; fixed
+// 32-frame runs took 16 rounds = 512).  The run length depends on the clip length only -- never on the batch size --
+// so a clip's partial sums, and with them its features, are bit-identical whatever its batch neighbours are.
+// MST_MELFEAT_BATCHES=n forces n*16-frame runs (used by the probes).
+int frames_per_run_of(const mst_plan* p, int /*B*/, int F) {
+  if (p->batches_per_run > 0) return p->batches_per_run * kTF;
+  int fpr = (F + 31) / 32;
+  fpr += fpr & 1;
+  return std::max(2 * kTF, fpr);
+}
+int runs_per_clip(const mst_plan* p, int B, int F) {
+  const int fpr = frames_per_run_of(p, B, F);
   return (F + fpr - 1) / fpr;
 }
 int pstride_of(const mst_plan* p) { return 4 * p->n_mels + kNumScalars; }
@@ -1086,8 +1098,7 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
   p->nc = n_fft / 2;
   p->nb = n_mels <= 128 ? 2 : 4;
   const char* env = getenv("MST_MELFEAT_BATCHES");
-  p->batches_per_run = env ? atoi(env) : 2;
-  if (p->batches_per_run < 1) p->batches_per_run = 1;
+  p->batches_per_run = env ? std::max(1, atoi(env)) : 0;   // 0: chosen per launch (frames_per_run_of)
   const int n_bins = n_fft / 2 + 1;
 
   // sparse mel table: per band contiguous support [start, start+len)
@@ -1167,7 +1178,7 @@ int mst_plan_feature_dim(const mst_plan* p) { return p ? p->feat_dim : MST_EINVA
 size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
   if (!p || B <= 0 || T <= 0) return 0;
   const int F = 1 + T / p->hop;
-  return mst::align_up((size_t)B * runs_per_clip(p, F) * pstride_of(p) * sizeof(float), 256);
+  return mst::align_up((size_t)B * runs_per_clip(p, B, F) * pstride_of(p) * sizeof(float), 256);
 }
 
 }  // extern "C"
@@ -1231,8 +1242,8 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
   kp.B = B, kp.T = T, kp.F = F, kp.M = p->n_mels, kp.hop = p->hop;
   kp.tw_count = p->tw_count, kp.nnz = p->nnz;
   for (int r = 0; r < 4; ++r) kp.glen[r] = p->glen[r], kp.goff[r] = p->goff[r];
-  kp.frames_per_run = p->batches_per_run * kTF;
-  kp.runs_per_clip = runs_per_clip(p, F);
+  kp.frames_per_run = frames_per_run_of(p, B, F);
+  kp.runs_per_clip = runs_per_clip(p, B, F);
   kp.pstride = pstride_of(p);
   bool base16 = true;
   for (int i = 0; i < 4; ++i) base16 = base16 && (reinterpret_cast<uintptr_t>(stems4[i]) & 15) == 0;
