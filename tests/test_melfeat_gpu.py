@@ -236,3 +236,27 @@ def test_device_stager_overlapped_h2d():
         assert torch.equal(outs[b][1].cpu(), batches[b])
         _, fr = ext.plan().forward(batches[b].cuda())
         assert torch.equal(outs[b][0], fr)
+
+
+@pytest.mark.parametrize("T", [1024, 4096 + 256 * 3, 256 * 33, 256 * 55 + 128, 256 * 97 + 4, 256 * 1024 + 252])
+def test_two_stage_a_kernels_agree_on_ragged_run_partitions(T):
+    """The stem-per-wave-pair kernel and the generic kernel share only the FFT helper; their frame / run / batch
+    bookkeeping is independent.  Lengths chosen so that the number of frames is not a multiple of the 16-frame batch,
+    of the run length, or of the hop (last partial frame), incl. one clip shorter than a run."""
+    x = torch.stack([cases.synth_clip(c, T) for c in (3, 8, 9)], 0)
+    ext = fe()
+    os.environ.pop("MST_MELFEAT_GENERIC", None)
+    f_spw, lm_spw = run(x, ext)
+    os.environ["MST_MELFEAT_GENERIC"] = "1"
+    try:
+        f_gen, lm_gen = run(x, ext)
+    finally:
+        os.environ.pop("MST_MELFEAT_GENERIC", None)
+    assert scaled_err(lm_spw, lm_gen) <= 2e-5
+    check_feats(f_spw, f_gen.numpy())
+    rf, rmel = ofeat.extract_all_features(x, return_mel=True)
+    check_logmel(lm_spw, torch.log(rmel + 1e-10), x=x)
+    check_feats(f_spw, rf)
+    # batch independence, bit for bit, for both kernels
+    f1, lm1 = run(x[1:2], ext)
+    assert torch.equal(f1[0], f_spw[1]) and torch.equal(lm1[0], lm_spw[1])
