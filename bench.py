@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--encoder", choices=["auto", "hip", "torch"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "f16x3", "f16x3-all"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "f16x3", "f16x3-all", "f16"], default="fp32",
                     help="conv1 arithmetic: exact fp32 MFMA (default) or opt-in 3-term split-precision f16 MFMA")
     ap.add_argument("--aug", action="store_true", help="also run the augmentation chain on the negative clip of every triplet inside the timed step (BASELINE configs[3] without SCNet)")
     ap.add_argument("--config", choices=["default", "baseline_sh", "config5"], default="default",
@@ -212,33 +212,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = t.item()
 
-    # opt-in split-precision mode, measured after (outside) the contract's timed region; the headline stays exact fp32
+    # opt-in precision modes, measured after (outside) the contract's timed region; the headline stays exact fp32
     alt = None
     if backend == "hip" and a.precision == "fp32" and not a.aug and a.ingest == "resident" and a.config == "default":
-        model.conv1_precision = "f16x3-all"
+        notes = {"f16x3-all": "conv1+conv2 on f16 MFMA with 3-term split precision, fp32 accumulate; embeddings within 1e-6 "
+                              "(rel. to max) of the exact-fp32 kernels, same 1e-4 parity tests",
+                 "f16": "conv1+conv2 with plain f16 operands, fp32 accumulate (the reference's --use_amp conv arithmetic); "
+                        "embeddings ~2e-4 of max from fp32: NOT within the 1e-4 parity bar, shown for headroom only"}
+        alt = []
         n_alt = max(5, a.steps // 2)
         main_marks = len(marks)
-        try:
-            for _ in range(3):
-                step(False)
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            for _ in range(n_alt):
-                step(False)
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-            tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-            alt = {"mode": "f16x3-all: conv1+conv2 on f16 MFMA with 3-term split precision, fp32 accumulate; embeddings "
-                           "within 1e-6 (rel. to max) of the exact-fp32 kernels, same 1e-4 parity tests",
-                   "value": round(world * a.triplets * n_alt / tb.item(), 3), "unit": "triplets/s",
-                   "ms_per_step": round(tb.item() / n_alt * 1e3, 4), "steps": n_alt}
-        except Exception as ex:  # e.g. activations too close to the f16 range: the mode refuses to run
-            alt = {"mode": "f16x3-all", "error": str(ex)[:200]}
+        for mode, note in notes.items():
+            model.conv1_precision = mode
+            try:
+                for _ in range(3):
+                    step(False)
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(n_alt):
+                    step(False)
+                if world > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+                alt.append({"mode": f"{mode}: {note}", "value": round(world * a.triplets * n_alt / tb.item(), 3),
+                            "unit": "triplets/s", "ms_per_step": round(tb.item() / n_alt * 1e3, 4), "steps": n_alt})
+            except Exception as ex:  # e.g. activations too close to the f16 range: the mode refuses to run
+                alt.append({"mode": mode, "error": str(ex)[:200]})
         model.conv1_precision = a.precision
         del marks[main_marks:]
 

@@ -537,7 +537,9 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 constexpr float kF16Scale = 1024.0f;  // weight pre-scale (folded back in the epilogue)
 constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
 
-template <int SUB>
+// TERMS = 3: split precision (fp32-equivalent, see above).  TERMS = 1: plain f16 operands (`x ~ xh`, `w ~ wh`), fp32
+// accumulate -- the arithmetic of the reference's `--use_amp` autocast convolutions (src/train.py:251-253), opt-in.
+template <int SUB, int TERMS>
 __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16,
                                                                   _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo) {
   using C = CC<1, SUB>;
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
           vl[cc] = (_Float16)(x - (float)h);
         }
         phi[r * PC + lane] = vh;
-        plo[r * PC + lane] = vl;
+        if (TERMS == 3) plo[r * PC + lane] = vl;
       }
     }
     nxt = decode(s + 1);
@@ -659,12 +661,12 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         bh[0][n] = wres[(n * 2 + 0) * 64 + lane];
-        bl[0][n] = wres[(n * 2 + 1) * 64 + lane];
+        if (TERMS == 3) bl[0][n] = wres[(n * 2 + 1) * 64 + lane];
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         ah[0][t] = phi[abase[t] + toff[0]];
-        al[0][t] = plo[abase[t] + toff[0]];
+        if (TERMS == 3) al[0][t] = plo[abase[t] + toff[0]];
       }
 #pragma unroll
       for (int st = 0; st < kF16Steps; ++st) {
@@ -673,12 +675,12 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             bh[nx][n] = wres[(((st + 1) * NT + n) * 2 + 0) * 64 + lane];
-            bl[nx][n] = wres[(((st + 1) * NT + n) * 2 + 1) * 64 + lane];
+            if (TERMS == 3) bl[nx][n] = wres[(((st + 1) * NT + n) * 2 + 1) * 64 + lane];
           }
 #pragma unroll
           for (int t = 0; t < MT; ++t) {
             ah[nx][t] = phi[abase[t] + toff[st + 1]];
-            al[nx][t] = plo[abase[t] + toff[st + 1]];
+            if (TERMS == 3) al[nx][t] = plo[abase[t] + toff[st + 1]];
           }
         }
 #pragma unroll
@@ -687,8 +689,10 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
         for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);  // small terms first
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bl[cu][n], acc[t][n], 0, 0, 0);
+            if (TERMS == 3) {
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);  // small terms first
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bl[cu][n], acc[t][n], 0, 0, 0);
+            }
             acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
               const size_t o = ((((size_t)cur.clip * p.nsub + cur.band) * p.out_rows + cur.tr) * p.out_cols + pc) * 32 + ch;
               const _Float16 h = (_Float16)m;
               out_hi[o] = h;
-              out_lo[o] = (_Float16)(m - (float)h);
+              if (TERMS == 3) out_lo[o] = (_Float16)(m - (float)h);
             }
           }
         }
@@ -735,6 +739,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 // shared by the 8 waves, every wave has a private 14x14-position patch).  Activations above the f16 range (65504)
 // would saturate: the Python wrapper checks max(pool1) once before enabling this mode.
 // ------------------------------------------------------------------------------------------
+template <int TERMS>
 __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ in_hi,
                                                                   const h16x8* __restrict__ in_lo,
                                                                   const h16x8* __restrict__ wfrag16) {
@@ -796,9 +801,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
       const bool ok = t.valid && e < NPOS && rin == rc && cin == cl;
       const size_t v = ((plane + rc) * p.in_cols + cl) * 4 + chunk;
       const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-      const h16x8 a = in_hi[v], b = in_lo[v];
+      const h16x8 a = in_hi[v];
       ph[i] = ok ? a : z;
-      pl[i] = ok ? b : z;
+      if (TERMS == 3) {
+        const h16x8 b = in_lo[v];
+        pl[i] = ok ? b : z;
+      }
     }
   };
 
@@ -812,7 +820,10 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = lane + 64 * i;
-      if (e < NPOS) phi[e] = ph[i], plo[e] = pl[i];
+      if (e < NPOS) {
+        phi[e] = ph[i];
+        if (TERMS == 3) plo[e] = pl[i];
+      }
     }
     __syncthreads();
     cur = nxt;
@@ -831,19 +842,21 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
-        bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
+        if (TERMS == 3) bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         ah[t] = phi[abase[t] + toff[st]];
-        al[t] = plo[abase[t] + toff[st]];
+        if (TERMS == 3) al[t] = plo[abase[t] + toff[st]];
       }
 #pragma unroll
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
+          if (TERMS == 3) {
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
+          }
           acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
         }
     }
@@ -1060,7 +1073,7 @@ struct mst_encoder {
   int num_cus = 256;
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
   void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
-  int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3
+  int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3, 3 conv1 + conv2 plain f16 (amp)
 };
 
 namespace {
@@ -1085,7 +1098,7 @@ WsLayout ws_layout(const mst_encoder* e, int B, int frames) {
   L.aff1 = take((size_t)B * ns * 32 * 8);
   L.aff2 = take((size_t)B * ns * 64 * 8);
   L.pool1 = take((size_t)B * ns * 32 * e->H1 * L.W1 * 4);
-  L.pool1_h16 = take(e->conv1_f16x3 == 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
+  L.pool1_h16 = take(e->conv1_f16x3 >= 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
   L.pool1_l16 = take(e->conv1_f16x3 == 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
   L.pool_in = take((size_t)B * e->C * L.W2 * 4);
   L.scores = take((size_t)B * L.W2 * 4);
@@ -1254,8 +1267,8 @@ void mst_encoder_destroy(mst_encoder* e) {
 
 int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
   MST_REQUIRE(e, "mst_encoder_set_precision: NULL encoder");
-  MST_REQUIRE(conv1_f16x3 == 0 || ((conv1_f16x3 == 1 || conv1_f16x3 == 2) && e->sub == 2),
-              "mst_encoder_set_precision: the f16x3 modes need the default 20-mel sub-bands (pool height 2)");
+  MST_REQUIRE(conv1_f16x3 == 0 || (conv1_f16x3 >= 1 && conv1_f16x3 <= 3 && e->sub == 2),
+              "mst_encoder_set_precision: the f16 modes (1, 2, 3) need the default 20-mel sub-bands (pool height 2)");
   e->conv1_f16x3 = conv1_f16x3;
   return MST_OK;
 }
@@ -1315,17 +1328,21 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
       static bool attr16 = false;
       if (!attr16) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
         attr16 = true;
       }
-      const bool both = e->conv1_f16x3 == 2;
+      const bool both = e->conv1_f16x3 >= 2;
       if (both && !(taps && taps->pool1)) cp.out = nullptr;   // fp32 pool1 only when a tap asks for it
-      hipLaunchKernelGGL((conv1_f16x3_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp,
-                         reinterpret_cast<const h16x8*>(e->w1frag16),
-                         both ? reinterpret_cast<_Float16*>(ws + L.pool1_h16) : nullptr,
-                         both ? reinterpret_cast<_Float16*>(ws + L.pool1_l16) : nullptr);
+      const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
+      _Float16* oh = both ? reinterpret_cast<_Float16*>(ws + L.pool1_h16) : nullptr;
+      _Float16* ol = e->conv1_f16x3 == 2 ? reinterpret_cast<_Float16*>(ws + L.pool1_l16) : nullptr;
+      if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
+      else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       err = hipGetLastError();
     } else if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
       using C = CC<1, 2>;
@@ -1358,18 +1375,23 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     const int g = std::min(grid, ns * cp.sets_per_band);
     hipError_t err;
-    if (e->conv1_f16x3 == 2) {
+    if (e->conv1_f16x3 >= 2) {
       constexpr size_t lds = (size_t)(kF16Steps * 4 * 2 * 64 + kConvWaves * 2 * 14 * 14) * 16;
       static bool attr = false;
       if (!attr) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 f16x3 attribute failed: %s", hipGetErrorString(err));
         attr = true;
       }
-      hipLaunchKernelGGL(conv2_f16x3_kernel, dim3(g), dim3(kConvThreads), lds, st, cp,
-                         reinterpret_cast<const h16x8*>(ws + L.pool1_h16), reinterpret_cast<const h16x8*>(ws + L.pool1_l16),
-                         reinterpret_cast<const h16x8*>(e->w2frag16));
+      const h16x8* ih = reinterpret_cast<const h16x8*>(ws + L.pool1_h16);
+      const h16x8* il = reinterpret_cast<const h16x8*>(ws + L.pool1_l16);
+      const h16x8* wf = reinterpret_cast<const h16x8*>(e->w2frag16);
+      if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv2_f16x3_kernel<1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, il, wf);
+      else hipLaunchKernelGGL((conv2_f16x3_kernel<3>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, il, wf);
       err = hipGetLastError();
     } else {
       err = launch_conv<2, 2>(cp, g, st);

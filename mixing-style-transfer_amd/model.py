@@ -197,12 +197,13 @@ class HipEncoder:
         h = C.c_void_p()
         _lib.check(_lib.lib().mst_encoder_create(C.byref(h), C.byref(self.cfg), C.byref(w)), "mst_encoder_create")
         self._h = h
-        modes = {"fp32": 0, "f16x3": 1, "f16x3-all": 2}
+        modes = {"fp32": 0, "f16x3": 1, "f16x3-all": 2, "f16": 3}
         if conv1_precision not in modes:
-            raise ValueError("conv precision must be 'fp32' (exact, default), 'f16x3' (conv1 on split-precision f16 MFMA) "
-                             "or 'f16x3-all' (conv1 and conv2)")
+            raise ValueError("conv precision must be 'fp32' (exact, default), 'f16x3' (conv1 on split-precision f16 MFMA), "
+                             "'f16x3-all' (conv1 and conv2) or 'f16' (plain f16 operands, fp32 accumulate: the "
+                             "arithmetic of the reference's --use_amp convolutions)")
         self.mode = modes[conv1_precision]
-        self._range_checked = self.mode != 2
+        self._range_checked = self.mode < 2
         _lib.check(_lib.lib().mst_encoder_set_precision(h, self.mode), "mst_encoder_set_precision")
         self._ws = None
         self.embed_dim = ae.attention_pooling.output_dim
@@ -225,7 +226,7 @@ class HipEncoder:
             _, t = self.forward(logmel[:1], feats[:1], taps=True)
             mx = t["pool1"].abs().max().item()
             if not mx < 3.0e4:
-                raise _lib.MstError(f"f16x3-all: conv1 activations reach {mx:.3g}, too close to the f16 range; use "
+                raise _lib.MstError(f"f16 conv2 input: conv1 activations reach {mx:.3g}, too close to the f16 range; use "
                                     f"conv precision 'f16x3' (conv1 only) or 'fp32'")
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
         if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:

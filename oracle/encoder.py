@@ -27,15 +27,25 @@ def film_params(sd, feats: torch.Tensor) -> torch.Tensor:
     return F.linear(h, sd[p + "film_head.weight"], sd[p + "film_head.bias"])
 
 
+def _f16_operand(t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """value after a round trip through float16 (optionally pre-scaled by a power of two so small weights stay normal)"""
+    return (t * scale).to(torch.float16).to(torch.float32) / scale
+
+
 def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int,
-                taps=None) -> torch.Tensor:
-    """model.py:127-157 for sub-band i.  x (B, 8, split, F) -> (B, 64, H', W')."""
+                taps=None, f16_operands=False) -> torch.Tensor:
+    """model.py:127-157 for sub-band i.  x (B, 8, split, F) -> (B, 64, H', W').
+    f16_operands: the arithmetic of the opt-in "f16" precision mode (and of the reference under `--use_amp` autocast,
+    src/train.py:251-253, for the convolutions): conv inputs and weights rounded to float16, products and sums in fp32."""
     p = f"audio_encoder.subnet_cnns.{i}."
     g1, b1, g2, b2 = torch.split(film[:, i * 192:(i + 1) * 192], [32, 32, 64, 64], dim=1)
     sub = max(1, split_size // 10)
 
     def block(x, conv, bn, g, b, pool):
-        x = F.conv2d(x, sd[p + conv + ".weight"], sd[p + conv + ".bias"], padding=3)
+        w = sd[p + conv + ".weight"]
+        if f16_operands:
+            x, w = _f16_operand(x), _f16_operand(w, 1024.0)
+        x = F.conv2d(x, w, sd[p + conv + ".bias"], padding=3)
         x = F.batch_norm(x, sd[p + bn + ".running_mean"], sd[p + bn + ".running_var"],
                          sd[p + bn + ".weight"], sd[p + bn + ".bias"], training=False, eps=1e-5)
         x = g[:, :, None, None] * x + b[:, :, None, None]
@@ -61,11 +71,11 @@ def attention_pool(sd, x: torch.Tensor) -> torch.Tensor:
 
 
 def encoder_from_logmel(sd, lm: torch.Tensor, feats: torch.Tensor, split_size=20, overlap=10,
-                        taps=None) -> torch.Tensor:
+                        taps=None, f16_operands=False) -> torch.Tensor:
     """log-mel (B, 8, M, F), features (B, Fd) -> embeddings (B, E).  model.py:290-382,508-542."""
     film = film_params(sd, feats)
     nsub = n_subbands(lm.shape[2], split_size, overlap)
-    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps)
+    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps, f16_operands)
             for i in range(nsub)]
     cat = torch.cat(outs, dim=1)  # (B, nsub*64, H', W')
     flat = cat.reshape(cat.shape[0], cat.shape[1] * cat.shape[2], cat.shape[3])

@@ -176,6 +176,34 @@ def test_conv_f16x3_split_precision_meets_the_fp32_bar(tag, T, mode):
     assert d_pool < 2e-6 and d_pin < 1e-5 and d_emb < 1e-5
 
 
+def test_conv_f16_amp_mode_matches_its_own_definition():
+    """Opt-in "f16" mode (1-term f16 MFMA = the reference's --use_amp conv arithmetic): conv inputs and weights are
+    rounded to float16, everything else is fp32.  Checked at 1e-4 against the oracle evaluated with exactly those
+    roundings, and reported against the exact path (the mode itself is a ~1e-3 approximation of fp32)."""
+    cfg = cases.CFG_DEFAULT
+    model, sd = build_model(cfg)
+    g = np.load(os.path.join(G, "encoder.npz"))
+    x = torch.stack([cases.synth_clip(c, 66150) for c in (0, 1)], 0)
+    feats = torch.from_numpy(g["default_short.features"])
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        e32 = model.hip_encoder().forward(lm, feats.cuda())
+        model.conv1_precision = "f16"
+        e16, t16 = model.hip_encoder().forward(lm, feats.cuda(), taps=True)
+        model.conv1_precision = "fp32"
+    taps = {}
+    want = oenc.encoder_from_logmel(sd, lm.cpu(), feats, cfg["split_size"], cfg["overlap"], taps, f16_operands=True)
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    p1 = t16["pool1"].cpu()
+    for i in (0, ns - 1):
+        close(p1[:, i], taps[f"pool1_{i}"])
+    close(t16["pool_in"].cpu(), taps["pool_in"])
+    close(e16.cpu(), want)
+    d = (e16 - e32).abs().max().item() / e32.abs().max().item()
+    print(f"f16 (amp) vs exact fp32 embeddings: {d:.2e} of max")
+    assert d < 2e-2
+
+
 def test_song_a_real_music_end_to_end():
     """BASELINE configs[0] on the GPU: real music through stage A + HIP encoder vs the reference goldens (bs=2)."""
     from test_melfeat_gpu import check_feats, check_logmel
