@@ -1,19 +1,23 @@
 """InfoNCE loss with the reference semantics (src/loss.py:10-136), vectorised (no per-anchor host syncs) and
-sharded: with torch.distributed initialised, embeddings and labels are all-gathered over RCCL/xGMI so every
-rank scores its local anchors against the global batch."""
+sharded: with torch.distributed initialised, embeddings and labels cross RCCL/xGMI in ONE packed all-gather and every
+rank evaluates the (tiny) loss on the whole gathered batch -- no other collective in forward or backward
+(SURVEY.md section 8e).  On CUDA/HIP tensors forward and backward run in libmst.so (`mst_infonce_forward/backward`);
+CPU tensors (the gloo tests of the sharding logic) take the same formulas in torch ops."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 
 class _AllGatherWithGrad(torch.autograd.Function):
-    """all-gather whose backward all-reduces the gradient of the gathered tensor and returns the local slice, so the
-    gradient w.r.t. the local embeddings includes the terms where they act as *columns* of other ranks' anchors."""
+    """all-gather of a (n, K) tensor; backward returns this rank's slice of the gradient of the gathered tensor.
+    `reduce_grad=True` first all-reduces that gradient -- needed when every rank differentiates only ITS OWN rows of the
+    loss, so that the local embeddings also receive the terms where they act as columns of other ranks' anchors.
+    InfoNCELoss does not need it: every rank evaluates the whole (replicated) loss on the gathered batch."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, reduce_grad):
         import torch.distributed as dist
-        ws, ctx.rank, ctx.n = dist.get_world_size(), dist.get_rank(), x.shape[0]
+        ws, ctx.rank, ctx.n, ctx.reduce_grad = dist.get_world_size(), dist.get_rank(), x.shape[0], reduce_grad
         out = torch.empty(ws * ctx.n, *x.shape[1:], dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous())
         return out
@@ -21,27 +25,29 @@ class _AllGatherWithGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         import torch.distributed as dist
-        g = g.contiguous().clone()
-        dist.all_reduce(g)
-        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n]
+        if ctx.reduce_grad:
+            g = g.contiguous().clone()
+            dist.all_reduce(g)
+        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n], None
 
 
-def gather_embeddings(emb: torch.Tensor, labels: torch.Tensor):
-    """All-gather (N_local, D) fp32 embeddings + (N_local,) int64 labels over RCCL/xGMI -> global tensors in rank
-    order, plus the row offset of the local slice.  Differentiable w.r.t. `emb` (see _AllGatherWithGrad)."""
+def gather_embeddings(emb: torch.Tensor, labels: torch.Tensor, reduce_grad=True):
+    """ONE all-gather over RCCL/xGMI of (N_local, D) fp32 embeddings with the int64 labels riding along as two extra
+    fp32 columns (bit patterns; the collective only copies bytes) -> global embeddings and labels in rank order, plus
+    the row offset of the local slice.  Differentiable w.r.t. `emb` (see _AllGatherWithGrad for `reduce_grad`)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return emb, labels, 0
-    ws, rank = dist.get_world_size(), dist.get_rank()
-    n = emb.shape[0]
-    all_l = torch.empty(ws * n, dtype=labels.dtype, device=labels.device)
-    dist.all_gather_into_tensor(all_l, labels.contiguous())
+    n, D = emb.shape
+    bits = labels.to(torch.int64).contiguous().view(torch.float32).view(n, 2)
+    packed = torch.cat([emb.float(), bits.to(emb.device)], dim=1)
     if emb.requires_grad:
-        all_e = _AllGatherWithGrad.apply(emb)
+        allp = _AllGatherWithGrad.apply(packed, reduce_grad)
     else:
-        all_e = torch.empty(ws * n, emb.shape[1], dtype=emb.dtype, device=emb.device)
-        dist.all_gather_into_tensor(all_e, emb.contiguous())
-    return all_e, all_l, rank * n
+        allp = torch.empty(dist.get_world_size() * n, D + 2, dtype=torch.float32, device=emb.device)
+        dist.all_gather_into_tensor(allp, packed)
+    all_l = allp[:, D:].detach().contiguous().view(torch.int64).view(-1).to(labels.dtype)
+    return allp[:, :D], all_l, dist.get_rank() * n
 
 
 def info_nce_rows(all_emb, all_labels, row0, rows, temperature):
@@ -117,22 +123,15 @@ class InfoNCELoss(nn.Module):
 
     def forward(self, embeddings, song_labels):
         if self.gather:
-            import torch.distributed as dist
-            all_e, all_l, row0 = gather_embeddings(embeddings, song_labels)
-            rows_fn = info_nce_rows_hip if all_e.is_cuda else info_nce_rows
-            s, c = rows_fn(all_e, all_l, row0, embeddings.shape[0], self.temperature)
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                sc = torch.stack([s.detach(), c.to(s.dtype)])
-                dist.all_reduce(sc)
-                if sc[1].item() == 0:
-                    raise RuntimeError("No positive pairs found in batch!")
-                # value: the global mean over all valid anchors (identical on every rank); gradient: this rank's share
-                # s / C_global -- summed over ranks (all-reduce SUM of parameter grads) it is the exact global gradient.
-                share = s / sc[1]
-                return share + (sc[0] / sc[1] - share).detach() if s.requires_grad else sc[0] / sc[1]
-        else:
-            rows_fn = info_nce_rows_hip if embeddings.is_cuda else info_nce_rows
-            s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
+            # sharded batch: one packed all-gather, then EVERY rank evaluates the whole loss on the gathered batch
+            # (N^2 D flops: negligible next to the encoder).  No all-reduce in the forward, none in the backward:
+            # the local slice of d loss / d all_embeddings is already complete, and the value is identical on all
+            # ranks.  Parameter gradients must be SUMMED over ranks (each rank holds the part that flows through
+            # its own clips).
+            all_e, all_l, _ = gather_embeddings(embeddings, song_labels, reduce_grad=False)
+            embeddings, song_labels = all_e, all_l
+        rows_fn = info_nce_rows_hip if embeddings.is_cuda else info_nce_rows
+        s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
         if c.item() == 0:
             raise RuntimeError(
                 f"No positive pairs found in batch! Batch size: {embeddings.shape[0]}, "
