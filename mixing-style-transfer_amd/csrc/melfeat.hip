@@ -644,8 +644,19 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 //   * the mixture energy comes from a short float4 pass over the batch's samples (just loaded: cache-resident).
 // Writes the same partial records as melfeat_kernel (same finalise kernel).
 // ------------------------------------------------------------------------------------------
-template <int NFFT, typename ST>
-__global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) {
+// WPS = waves per stem: the workgroup has 4*WPS waves and works on batches of 2*WPS... frames: with WPS = 3 (12 waves,
+// 3 per SIMD, 168 VGPRs) the batch is 6 frames (2 per wave), which is what the 160 KB of LDS leave for the tile once
+// twelve 9.2 KB FFT scratches are resident; WPS = 2 is the 8-wave / 16-frame layout.
+template <int WPS>
+struct SpwGeom {
+  static constexpr int WAVES = 4 * WPS, THREADS = WAVES * 64;
+  static constexpr int FPW = WPS == 2 ? 8 : 2;     // frames per wave per batch
+  static constexpr int TF = WPS * FPW;             // frames per batch
+};
+
+template <int NFFT, typename ST, int WPS>
+__global__ __launch_bounds__(SpwGeom<WPS>::THREADS) void melfeat_spw_kernel(const KParams p) {
+  constexpr int kWaves = SpwGeom<WPS>::WAVES, kThreads = SpwGeom<WPS>::THREADS, kTF = SpwGeom<WPS>::TF;
   constexpr int NB = 2, NOWN = NFFT / 256;
   constexpr int SCR = NFFT + NFFT / 8;
   constexpr float kLn2 = 0.69314718055994530942f;
@@ -677,7 +688,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
     return static_cast<const ST*>(p.stem[c >> 1]) + (size_t)clip * p.clip_stride + (size_t)(c & 1) * p.T;
   };
   float* part = p.partials + ((size_t)clip * p.runs_per_clip + run) * p.pstride;
-  const int stem = wave >> 1, half = wave & 1;
+  const int stem = wave / WPS, half = wave % WPS;   // `half`: which of the stem's WPS waves
   const ST* const xs[2] = {chan(2 * stem), chan(2 * stem + 1)};
   const int o_begin = f_begin * p.hop;
   const int o_end = (f_end == p.F) ? p.T : min(p.T, f_end * p.hop);
@@ -694,8 +705,8 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
   for (int fb = f_begin; fb < f_end; fb += kTF) {
     // ---- phase A: every wave: 8 frames of its stem, L and R as one complex FFT
 #pragma unroll 1
-    for (int i = 0; i < kTF / 2; ++i) {
-      const int fr = fb + 2 * i + half;
+    for (int i = 0; i < kTF / WPS; ++i) {
+      const int fr = fb + WPS * i + half;
       if (fr >= f_end) break;  // wave-uniform
       float mel[2][NB];
       float2 raw[NOWN];        // (L, R) of the samples the frame owns
@@ -803,22 +814,34 @@ __global__ __launch_bounds__(kThreads) void melfeat_spw_kernel(const KParams p) 
   for (int i = tid; i < 4 * NB * 64; i += kThreads) {
     const int l = i & 63, r = (i >> 6) % NB, s = i / (64 * NB);
     const int band = p.lanebands[r * 64 + l].band;
-    if (band >= 0) part[s * M + band] = red[((2 * s) * NB + r) * 64 + l] + red[((2 * s + 1) * NB + r) * 64 + l];
+    if (band >= 0) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WPS; ++w) v += red[((WPS * s + w) * NB + r) * 64 + l];
+      part[s * M + band] = v;
+    }
   }
-  if (tid < 4) {  // per-stem scalars: waves 2s and 2s+1
+  if (tid < 4) {  // per-stem scalars: waves WPS*s .. WPS*s + WPS-1
     const int s = tid;
-    const float* a = red2 + (2 * s) * 24;
-    const float* b = a + 24;
+    float v[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) v[k] = 0.f;
+    for (int w = 0; w < WPS; ++w) {
+      const float* a = red2 + (WPS * s + w) * 24;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) v[k] += a[k];
+      v[12] = fmaxf(v[12], a[12]), v[13] = fmaxf(v[13], a[13]);
+    }
     float* q = part + 4 * M;
-    q[S_LOGSUM + s] = a[0] + b[0];
-    q[S_LINSUM + s] = a[1] + b[1];
-    q[S_SQ + 2 * s] = a[2] + b[2], q[S_SQ + 2 * s + 1] = a[3] + b[3];
-    q[S_DSUM + 2 * s] = a[4] + b[4], q[S_DSUM + 2 * s + 1] = a[5] + b[5];
-    q[S_DSQ + 2 * s] = a[6] + b[6], q[S_DSQ + 2 * s + 1] = a[7] + b[7];
-    q[S_CROSS + s] = a[8] + b[8];
-    q[S_MID + s] = a[9] + b[9];
-    q[S_SIDE + s] = a[10] + b[10];
-    q[S_PEAK + 2 * s] = fmaxf(a[12], b[12]), q[S_PEAK + 2 * s + 1] = fmaxf(a[13], b[13]);
+    q[S_LOGSUM + s] = v[0];
+    q[S_LINSUM + s] = v[1];
+    q[S_SQ + 2 * s] = v[2], q[S_SQ + 2 * s + 1] = v[3];
+    q[S_DSUM + 2 * s] = v[4], q[S_DSUM + 2 * s + 1] = v[5];
+    q[S_DSQ + 2 * s] = v[6], q[S_DSQ + 2 * s + 1] = v[7];
+    q[S_CROSS + s] = v[8];
+    q[S_MID + s] = v[9];
+    q[S_SIDE + s] = v[10];
+    q[S_PEAK + 2 * s] = v[12], q[S_PEAK + 2 * s + 1] = v[13];
     float mk = 0.f;
     for (int w = 0; w < kWaves; ++w) mk += red2[w * 24 + 14 + s];
     q[S_MASK + s] = mk;
@@ -1002,16 +1025,16 @@ hipError_t launch_melfeat(const KParams& kp, int grid, size_t lds, hipStream_t s
   return hipGetLastError();
 }
 
-template <int NFFT, typename ST>
+template <int NFFT, typename ST, int WPS>
 hipError_t launch_melfeat_spw(const KParams& kp, int grid, size_t lds, hipStream_t st) {
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_spw_kernel<NFFT, ST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_spw_kernel<NFFT, ST, WPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_lds = lds;
   }
-  hipLaunchKernelGGL((melfeat_spw_kernel<NFFT, ST>), dim3(grid), dim3(kThreads), lds, st, kp);
+  hipLaunchKernelGGL((melfeat_spw_kernel<NFFT, ST, WPS>), dim3(grid), dim3(SpwGeom<WPS>::THREADS), lds, st, kp);
   return hipGetLastError();
 }
 
@@ -1266,15 +1289,24 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
   const int grid = B * kp.runs_per_clip;
   hipError_t e = hipErrorInvalidValue;
   // stem-per-wave-pair kernel for the standard configuration; the generic kernel covers everything else
-  const size_t lds_spw = (size_t)(nc + p->tw2_count + kWaves * (p->n_fft + p->n_fft / 8)) * sizeof(float2) +
-                         (size_t)(((p->nnz + 3) & ~3) + kTF * (8 * p->n_mels + 1)) * sizeof(float);
-  const bool spw = kp.vec_ok && kp.vec4_ok && p->hop * 4 == p->n_fft && p->n_mels <= 128 && p->nb == 2 &&
-                   (p->n_fft == 512 || p->n_fft == 1024) && lds_spw <= 160 * 1024 && !getenv("MST_MELFEAT_GENERIC");
-  if (spw) {
+  // stem-per-wave-pair kernel for the standard configuration; the generic kernel covers everything else
+  const int wps = getenv("MST_SPW_WPS") ? atoi(getenv("MST_SPW_WPS")) : 3;
+  auto spw_lds = [&](int w) {
+    return (size_t)(nc + p->tw2_count + 4 * w * (p->n_fft + p->n_fft / 8)) * sizeof(float2) +
+           (size_t)(((p->nnz + 3) & ~3) + (w == 2 ? 16 : 6) * (8 * p->n_mels + 1)) * sizeof(float);
+  };
+  const bool spw_ok = kp.vec_ok && kp.vec4_ok && p->hop * 4 == p->n_fft && p->n_mels <= 128 && p->nb == 2 &&
+                      (p->n_fft == 512 || p->n_fft == 1024) && !getenv("MST_MELFEAT_GENERIC");
+  const bool spw3 = spw_ok && wps == 3 && p->n_fft == 1024 && spw_lds(3) <= 160 * 1024;
+  const bool spw = spw3 || (spw_ok && spw_lds(2) <= 160 * 1024);
+  if (spw3) {
+    e = pcm16 ? launch_melfeat_spw<1024, short, 3>(kp, grid, spw_lds(3), st) : launch_melfeat_spw<1024, float, 3>(kp, grid, spw_lds(3), st);
+  } else if (spw) {
+    const size_t lds_spw = spw_lds(2);
     if (p->n_fft == 1024)
-      e = pcm16 ? launch_melfeat_spw<1024, short>(kp, grid, lds_spw, st) : launch_melfeat_spw<1024, float>(kp, grid, lds_spw, st);
+      e = pcm16 ? launch_melfeat_spw<1024, short, 2>(kp, grid, lds_spw, st) : launch_melfeat_spw<1024, float, 2>(kp, grid, lds_spw, st);
     else
-      e = pcm16 ? launch_melfeat_spw<512, short>(kp, grid, lds_spw, st) : launch_melfeat_spw<512, float>(kp, grid, lds_spw, st);
+      e = pcm16 ? launch_melfeat_spw<512, short, 2>(kp, grid, lds_spw, st) : launch_melfeat_spw<512, float, 2>(kp, grid, lds_spw, st);
   } else {
 #define MST_CASE(NF)                                                                                          \
   case NF:                                                                                                    \
