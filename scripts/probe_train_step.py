@@ -1,0 +1,41 @@
+"""Train-step timing of the CURRENT training path (stage A + loss in HIP, encoder fwd/bwd on PyTorch-ROCm/MIOpen):
+the number a native backward has to beat.  Run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mst_amd.loss import InfoNCELoss
+from mst_amd.mixing_utils import MixingFeatureExtractor
+from mst_amd.model import MixingStyleEncoder
+from mst_amd.synth import synth_batch
+
+B, T = int(os.environ.get("B", 72)), 441000
+torch.manual_seed(0)
+model = MixingStyleEncoder(44100, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).cuda().train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+fe = MixingFeatureExtractor()
+crit = InfoNCELoss(0.1)
+x = synth_batch(B, T, device="cuda")
+stems = {s: x[:, 2 * i:2 * i + 2] for i, s in enumerate(("vocals", "bass", "drums", "other"))}
+labels = torch.arange(B, device="cuda") // 3
+
+def step():
+    with torch.no_grad():
+        feats, logmel = fe.features_and_logmel(stems)
+    emb = model.forward_from_logmel(logmel, feats)
+    loss = crit(emb, labels)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    opt.step()
+    return loss
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    l = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"B={B}: train step {dt * 1e3:.1f} ms = {B / 3 / dt:.1f} triplets/s, loss {l.item():.4f}, "
+      f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
