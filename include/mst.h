@@ -144,6 +144,26 @@ int mst_encoder_forward(const mst_encoder* enc, const float* logmel, int frames,
                         int B, float* emb, const mst_encoder_taps* taps, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Training forward (first half): the same network with train-mode BatchNorm -- batch statistics over
+ * (B, H, W) per (sub-band, channel), biased variance, as nn.BatchNorm2d in training mode (src/model.py:107-125 under
+ * model.train()) -- and Dropout as identity (pass p = 0 modules; dropout masks are the caller's business until the
+ * backward kernels land).  The raw convolution outputs are kept in the workspace in accumulator order for the
+ * backward pass.  taps (all optional, device): film / pool1 / pool_in as above; bn1 [n_sub][32][2], bn2 [n_sub][64][2]
+ * = (batch mean, 1/sqrt(biased var + eps)) -- the caller updates its running statistics from them.
+ * Needs the default 20-mel sub-bands.  Workspace: mst_encoder_train_workspace_bytes (3.6 GB + 1.1 GB of saved
+ * activations at 72 clips of 10 s).                                                                           */
+typedef struct mst_encoder_train_taps {
+  float* film;
+  float* pool1;
+  float* pool_in;
+  float* bn1;
+  float* bn2;
+} mst_encoder_train_taps;
+size_t mst_encoder_train_workspace_bytes(const mst_encoder* enc, int B, int frames);
+int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int frames, const float* feats, int B,
+                              float* emb, const mst_encoder_train_taps* taps, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Augmentation chain.  Replaces AudioAugmenter.augment_stems src/mixing_utils.py:376-419 and
  * apply_spectral_tilt :421-433, apply_compression :435-447, apply_bandwidth_limit :449-456,

@@ -39,6 +39,11 @@ class EncoderTaps(C.Structure):
     _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("events", C.c_void_p * 6)]
 
 
+class EncoderTrainTaps(C.Structure):
+    _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("bn1", C.c_void_p),
+                ("bn2", C.c_void_p)]
+
+
 class AugStem(C.Structure):
     _fields_ = [("gain", C.c_float), ("tilt", C.c_int32), ("compress", C.c_int32), ("bw_sections", C.c_int32),
                 ("tilt_sos", C.c_double * 6), ("bw_sos", C.c_double * 12)]
@@ -72,6 +77,9 @@ SYMBOLS = {
     "mst_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.POINTER(EncoderTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "mst_encoder_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_aug_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mst_aug_apply": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_size_t, C.c_void_p]),

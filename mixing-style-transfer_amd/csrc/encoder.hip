@@ -146,7 +146,31 @@ struct ConvParams {
   int out_rows, out_cols;     // pooled plane per (band, channel)
   int tiles_r, tiles_c;       // wave tiles per (band, clip)
   int sets_per_band;          // ceil(B * tiles_r * tiles_c / 8)
+  // MODE 1 (training forward): the raw convolution output + bias is stored in ACCUMULATOR ORDER,
+  //   yraw[clip][band][tr][tc][n][lane][e]   e < 4*MT (the lane's accumulator slots of N-tile n),
+  // which is exactly how the pooling windows sit in registers (the apply / backward kernels work per lane again) and
+  // how a later weight-gradient MFMA wants its A operand; per-(band, channel) sums of y and y^2 over the valid
+  // positions go to stats[band][COUT][2] (double) for the batch statistics of train-mode BatchNorm.
+  float* yraw;
+  double* stats;
+  const float* bias;          // [nsub][COUT]
+  int raw_rows, raw_cols;     // valid extent of the convolution output plane
 };
+
+// fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
+template <int NT, int COUT>
+__device__ __forceinline__ void flush_stats(double (&st)[NT][2], double* stats, int band, int lane) {
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      double x = st[n][k];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      if (lane < 16) atomicAdd(&stats[((size_t)band * COUT + n * 16 + lane) * 2 + k], x);
+      st[n][k] = 0.0;
+    }
+}
 
 struct Tile {
   int valid, clip, band, tr, tc;
@@ -164,10 +188,11 @@ struct ConvGeom {
   static constexpr int NCV = C::RL >= 64 ? C::RL / 64 : 1;                      // column variants of the loader
 };
 
-template <int LAYER, int SUB>
+template <int LAYER, int SUB, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) {
   using C = CC<LAYER, SUB>;
   using GEO = ConvGeom<LAYER, SUB>;
+  static_assert(MODE == 0 || LAYER == 2, "raw mode: conv2 here, conv1 in conv1_resident_kernel");
   constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
   constexpr int WBP = GEO::WBP, PATCH = GEO::PATCH, NWF = GEO::NWF, NPF = GEO::NPF, NCV = GEO::NCV;
   constexpr int NPIECE = NPF + NWF, PPT = (NPIECE + 48) / 49;  // prefetch pieces, pieces issued per tap
@@ -267,6 +292,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
   };
 
   f32x4 acc[MT][NT];
+  double st[NT][2];
+  int st_band = -1;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) st[n][0] = st[n][1] = 0.0;
   Tile cur{}, nxt{};
   nxt = decode(0);
   if (nq > 0) {
@@ -329,7 +358,33 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
         }
       }
     }
-    if (chunk == NCH - 1 && cur.valid) {
+    if (MODE == 1 && chunk == NCH - 1 && cur.valid) {
+      // training forward: raw output + bias in accumulator order, batch-statistics sums over the valid positions
+      const int j = lane & 15, g = lane >> 4;
+      if (cur.band != st_band) {
+        if (st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
+        st_band = cur.band;
+      }
+      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.tiles_r + cur.tr) * p.tiles_c + cur.tc) *
+                               (size_t)(NT * 64 * 4 * MT);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float b = p.bias[cur.band * C::COUT + n * 16 + j];
+        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = acc[t][n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] += b;
+            const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
+            if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
+          }
+          dst[t] = v;
+        }
+      }
+    }
+    if (MODE == 0 && chunk == NCH - 1 && cur.valid) {
       // epilogue: y = A*acc + C, ReLU, max over the window, all in this lane's registers
       const int j = lane & 15, g = lane >> 4;
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
@@ -364,6 +419,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
       }
     }
   }
+  if (MODE == 1 && st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -373,7 +429,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 // of one wave overlaps the MFMAs of its SIMD partner.  Workgroups own contiguous runs of sets, so the band (and
 // with it the LDS weight image) changes at most once per workgroup.
 // ------------------------------------------------------------------------------------------
-template <int SUB>
+template <int SUB, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const ConvParams p) {
   using C = CC<1, SUB>;
   constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
@@ -441,6 +497,9 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   };
 
   f32x4 acc[MT][NT];
+  double st[NT][2];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) st[n][0] = st[n][1] = 0.0;
   int cur_band = -1;
   Tile cur{}, nxt = decode(s_begin);
   prefetch_setup(nxt);
@@ -450,6 +509,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   for (int s = s_begin; s < s_end; ++s) {
     cur = nxt;
     if (cur.band != cur_band) {  // same `s` sequence in every wave: all eight reach this together
+      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
       __syncthreads();
       for (int c = 0; c < 2; ++c) {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)cur.band * 2 + c) * WBP);
@@ -499,6 +559,29 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         }
       }
     }
+    if constexpr (MODE == 1) {
+      // training forward: raw output + bias in accumulator order, batch-statistics sums over the valid columns
+      const int j = lane & 15, g = lane >> 4;
+      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.tiles_r + cur.tr) * p.tiles_c + cur.tc) *
+                               (size_t)(NT * 64 * 4 * MT);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float b = p.bias[cur.band * C::COUT + n * 16 + j];
+        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = acc[t][n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] += b;
+            const int e = 4 * t + r, wv = e / C::WIN, pos = e % C::WIN;
+            const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
+            if (col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
+          }
+          dst[t] = v;
+        }
+      }
+    } else
     {
       const int j = lane & 15, g = lane >> 4;
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
@@ -522,6 +605,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
       }
     }
   }
+  if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,6 +1158,8 @@ struct mst_encoder {
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
   void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
   int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3, 3 conv1 + conv2 plain f16 (amp)
+  // un-folded parameters for the training forward (batch-statistics BatchNorm)
+  float *c1b = nullptr, *bn1w = nullptr, *bn1b = nullptr, *c2b = nullptr, *bn2w = nullptr, *bn2b = nullptr;
 };
 
 namespace {
@@ -1128,6 +1214,91 @@ std::vector<float> conv_fragments(const float* w, int nsub, int cout, int cin, i
                 w[(((size_t)b * cout + co) * cin + ci) * 49 + tap];
           }
   return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Training forward (first half): train-mode BatchNorm needs the statistics of the whole batch before
+// anything downstream of the convolution can be computed, so the fused eval kernels are split in two:
+//   conv (MODE 1)  ->  yraw (accumulator order) + per-(band, channel) sums        [conv kernels above]
+//   bn_fold_kernel ->  batch mean / 1/std, and the per-(clip, band, channel) affine  A*y + C  that carries
+//                      BatchNorm(batch statistics) and FiLM, as in eval
+//   apply_kernel   ->  affine + ReLU + max-pool per lane (the pooling window is the lane's own 10 / 16 values)
+// yraw is kept: the backward pass recomputes everything between y and the pooled output from it.
+// ------------------------------------------------------------------------------------------
+struct FoldParams {
+  const double* stats;     // [nsub][COUT][2]
+  const float *bn_w, *bn_b;  // [nsub][COUT]
+  const float* film;       // [B][nsub*192]
+  float2* aff;             // [B][nsub][COUT]
+  float2* bnstat;          // [nsub][COUT] (batch mean, 1/sqrt(biased var + eps))
+  double count;            // positions per (band, channel): B * rows * cols
+  float eps;
+  int nsub, cout, goff, boff;   // FiLM gamma / beta offsets inside a band's 192 values
+};
+
+__global__ void bn_fold_kernel(const FoldParams p) {   // grid (nsub, B), block COUT
+  const int band = blockIdx.x, b = blockIdx.y, ch = threadIdx.x;
+  const size_t i = (size_t)band * p.cout + ch;
+  const double mean = p.stats[i * 2] / p.count;
+  const double var = fmax(p.stats[i * 2 + 1] / p.count - mean * mean, 0.0);
+  const double invstd = 1.0 / sqrt(var + (double)p.eps);
+  if (b == 0) p.bnstat[i] = make_float2((float)mean, (float)invstd);
+  const float* fl = p.film + ((size_t)b * p.nsub + band) * 192;
+  const double g = fl[p.goff + ch], be = fl[p.boff + ch];
+  const double sc = (double)p.bn_w[i] * invstd;
+  p.aff[((size_t)b * p.nsub + band) * p.cout + ch] =
+      make_float2((float)(g * sc), (float)(g * ((double)p.bn_b[i] - sc * mean) + be));
+}
+
+struct ApplyParams {
+  const float* yraw;
+  const float2* aff;
+  float* out;
+  int B, nsub, tiles_r, tiles_c, out_rows, out_cols;
+  long long units;   // B * nsub * tiles_r * tiles_c * NT * 64
+};
+
+template <int LAYER>
+__global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
+  using C = CC<LAYER, 2>;
+  constexpr int NT = C::NT, NV = 4 * C::MT;
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= p.units) return;
+  const int lane = (int)(u & 63), n = (int)((u >> 6) % NT);
+  long long tile = (u >> 6) / NT;
+  const int tc = (int)(tile % p.tiles_c);
+  tile /= p.tiles_c;
+  const int tr = (int)(tile % p.tiles_r);
+  tile /= p.tiles_r;
+  const int band = (int)(tile % p.nsub), clip = (int)(tile / p.nsub);
+  const int j = lane & 15, g = lane >> 4, ch = n * 16 + j;
+  const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
+  const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (size_t)u * NV);
+  float v[NV];
+#pragma unroll
+  for (int t = 0; t < C::MT; ++t) {
+    const f32x4 q = src[t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
+  }
+  if constexpr (LAYER == 1) {
+#pragma unroll
+    for (int wv = 0; wv < C::WPG; ++wv) {
+      float m = 0.f;
+#pragma unroll
+      for (int pos = 0; pos < C::WIN; ++pos) m = fmaxf(m, fmaf(v[wv * C::WIN + pos], ac.x, ac.y));
+      const int pc = 4 * C::WPG * tc + C::WPG * g + wv;
+      if (pc < p.out_cols)
+        p.out[((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + tr) * p.out_cols + pc] = m;
+    }
+  } else {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) m = fmaxf(m, fmaf(v[e], ac.x, ac.y));
+    const int pr = 2 * tr + (g >> 1), pc = 2 * tc + (g & 1);
+    if (pr < p.out_rows && pc < p.out_cols)
+      p.out[(((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows * p.out_cols + (size_t)pr * p.out_cols + pc] = m;
+  }
 }
 
 template <int LAYER, int SUB>
@@ -1245,6 +1416,8 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projfrag, pfrag); UP(att0frag, af);
   UPP(b0, w->mlp0_b, H); UPP(b3, w->mlp3_b, H); UPP(hb, w->head_b, ns * 192);
   UPP(att0_b, w->att0_b, A); UPP(att2_w, w->att2_w, A); UPP(proj_b, w->proj_b, E);
+  UPP(c1b, w->conv1_b, ns * 32); UPP(bn1w, w->bn1_w, ns * 32); UPP(bn1b, w->bn1_b, ns * 32);
+  UPP(c2b, w->conv2_b, ns * 64); UPP(bn2w, w->bn2_w, ns * 64); UPP(bn2b, w->bn2_b, ns * 64);
 #undef UP
 #undef UPP
   if (rc) {
@@ -1258,7 +1431,8 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
 void mst_encoder_destroy(mst_encoder* e) {
   if (!e) return;
   float* ptrs[] = {e->w1frag, e->w2frag, e->s1, e->t1, e->s2, e->t2, e->w0t, e->b0, e->w3t, e->b3, e->hwt,
-                   e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b};
+                   e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b, e->c1b, e->bn1w, e->bn1b, e->c2b,
+                   e->bn2w, e->bn2b};
   for (float* q : ptrs) (void)hipFree(q);
   (void)hipFree(e->w1frag16);
   (void)hipFree(e->w2frag16);
@@ -1422,6 +1596,160 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     MST_HIP_CHECK(hipGetLastError());
   }
   mark(5);
+  return MST_OK;
+}
+
+// ---- training forward ---------------------------------------------------------------------------------------------
+namespace {
+struct TrainLayout {
+  WsLayout base;
+  size_t y1, y2, stats1, stats2, bn1, bn2, total;
+  int tr1, tc1, tr2, tc2;
+};
+TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
+  TrainLayout T{};
+  T.base = ws_layout(e, B, frames);
+  const int ns = e->cfg.n_subbands;
+  T.tr1 = e->H1, T.tc1 = (frames + 39) / 40;                 // conv1 tiles: 2 rows x 40 columns, ALL columns (statistics)
+  T.tr2 = (e->H1 + 7) / 8, T.tc2 = (T.base.W1 + 7) / 8;      // conv2 tiles: 8 x 8, ALL rows
+  size_t o = T.base.total;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += mst::align_up(bytes, 256);
+    return at;
+  };
+  T.y1 = take((size_t)B * ns * T.tr1 * T.tc1 * 2 * 64 * 20 * 4);
+  T.y2 = take((size_t)B * ns * T.tr2 * T.tc2 * 4 * 64 * 16 * 4);
+  T.stats1 = take((size_t)ns * 32 * 2 * 8);
+  T.stats2 = take((size_t)ns * 64 * 2 * 8);
+  T.bn1 = take((size_t)ns * 32 * 8);
+  T.bn2 = take((size_t)ns * 64 * 8);
+  T.total = o;
+  return T;
+}
+}  // namespace
+
+size_t mst_encoder_train_workspace_bytes(const mst_encoder* e, int B, int frames) {
+  if (!e || B <= 0 || frames < 20 || e->sub != 2) return 0;
+  return train_layout(e, B, frames).total;
+}
+
+int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
+                              const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && logmel && feats && emb, "mst_encoder_forward_train: NULL argument");
+  MST_REQUIRE(e->sub == 2, "mst_encoder_forward_train: needs the default 20-mel sub-bands (pool height 2)");
+  MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward_train: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
+  const TrainLayout T = train_layout(e, B, frames);
+  const WsLayout& L = T.base;
+  MST_REQUIRE(L.W2 >= 1, "mst_encoder_forward_train: clip too short for two pooling stages (frames=%d)", frames);
+  if (!workspace || workspace_bytes < T.total)
+    return mst::fail(MST_ENOMEM, "mst_encoder_forward_train: workspace %zu B < required %zu B", workspace_bytes, T.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int ns = e->cfg.n_subbands;
+  float* film = (taps && taps->film) ? taps->film : reinterpret_cast<float*>(ws + L.film);
+  float* pool1 = (taps && taps->pool1) ? taps->pool1 : reinterpret_cast<float*>(ws + L.pool1);
+  float* pool_in = (taps && taps->pool_in) ? taps->pool_in : reinterpret_cast<float*>(ws + L.pool_in);
+  float2* aff1 = reinterpret_cast<float2*>(ws + L.aff1);
+  float2* aff2 = reinterpret_cast<float2*>(ws + L.aff2);
+  float* scores = reinterpret_cast<float*>(ws + L.scores);
+  float* y1 = reinterpret_cast<float*>(ws + T.y1);
+  float* y2 = reinterpret_cast<float*>(ws + T.y2);
+  double* stats1 = reinterpret_cast<double*>(ws + T.stats1);
+  double* stats2 = reinterpret_cast<double*>(ws + T.stats2);
+  MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * 8, st));
+  MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * 8, st));
+  {   // FiLM MLP (its eval-mode affines are overwritten by bn_fold_kernel below)
+    FilmParams fp{feats, e->w0t, e->b0, e->w3t, e->b3, e->hwt, e->hb, e->s1, e->t1, e->s2, e->t2,
+                  film, aff1, aff2, e->cfg.feature_dim, e->cfg.film_hidden, ns};
+    const int groups = ns < 4 ? ns : 4;
+    const int bpg = (ns + groups - 1) / groups;
+    const size_t lds = (size_t)(e->cfg.feature_dim + 2 * e->cfg.film_hidden + bpg * 192) * sizeof(float);
+    hipLaunchKernelGGL(film_kernel, dim3(B, groups), dim3(256), lds, st, fp);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  const int grid = e->num_cus;
+  hipError_t err;
+  {   // conv1 raw + statistics
+    ConvParams cp{};
+    cp.in = logmel, cp.wfrag = e->w1frag, cp.B = B, cp.nsub = ns;
+    cp.in_rows = e->cfg.split_size, cp.in_cols = frames;
+    cp.in_cstride = e->cfg.n_mels * frames;
+    cp.in_bandoff = e->cfg.overlap * frames;
+    cp.in_clipstride = (long long)8 * e->cfg.n_mels * frames;
+    cp.out_rows = e->H1, cp.out_cols = L.W1;
+    cp.tiles_r = T.tr1, cp.tiles_c = T.tc1;
+    cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+    cp.yraw = y1, cp.stats = stats1, cp.bias = e->c1b, cp.raw_rows = e->cfg.split_size, cp.raw_cols = frames;
+    const int g = std::min(grid, ns * cp.sets_per_band);
+    using C = CC<1, 2>;
+    constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (train) attribute failed: %s", hipGetErrorString(err));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv1_resident_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
+    MST_HIP_CHECK(hipGetLastError());
+    float2* bnstat = (taps && taps->bn1) ? reinterpret_cast<float2*>(taps->bn1) : reinterpret_cast<float2*>(ws + T.bn1);
+    FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, (double)B * e->cfg.split_size * frames, e->cfg.bn_eps,
+                  ns, 32, 0, 32};
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
+    ApplyParams ap{y1, aff1, pool1, B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64};
+    hipLaunchKernelGGL((apply_kernel<1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  {   // conv2 raw + statistics (all 10 rows: rows 8, 9 never reach MaxPool(4,4) but count in the batch statistics)
+    ConvParams cp{};
+    cp.in = pool1, cp.wfrag = e->w2frag, cp.B = B, cp.nsub = ns;
+    cp.in_rows = e->H1, cp.in_cols = L.W1;
+    cp.in_cstride = e->H1 * L.W1;
+    cp.in_bandoff = 32 * e->H1 * L.W1;
+    cp.in_clipstride = (long long)ns * 32 * e->H1 * L.W1;
+    cp.out_rows = e->FD, cp.out_cols = L.W2;
+    cp.tiles_r = T.tr2, cp.tiles_c = T.tc2;
+    cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+    cp.yraw = y2, cp.stats = stats2, cp.bias = e->c2b, cp.raw_rows = e->H1, cp.raw_cols = L.W1;
+    const int g = std::min(grid, ns * cp.sets_per_band);
+    using GEO = ConvGeom<2, 2>;
+    const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<2, 2, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 (train) attribute failed: %s", hipGetErrorString(err));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
+    MST_HIP_CHECK(hipGetLastError());
+    float2* bnstat = (taps && taps->bn2) ? reinterpret_cast<float2*>(taps->bn2) : reinterpret_cast<float2*>(ws + T.bn2);
+    FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
+    ApplyParams ap{y2, aff2, pool_in, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
+    hipLaunchKernelGGL((apply_kernel<2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  {
+    AttnParams ap{pool_in, e->att0frag, e->att0_b, e->att2_w, e->att2_b, scores, B, e->C, L.W2, e->cfg.attn_hidden};
+    const int mtiles = (B * L.W2 + 15) / 16;
+    hipLaunchKernelGGL(attn_scores_kernel, dim3(mtiles), dim3(256), 0, st, ap);
+    MST_HIP_CHECK(hipGetLastError());
+    float* pooled = reinterpret_cast<float*>(ws + L.pooled);
+    PoolParams pp{pool_in, scores, pooled, e->C, L.W2};
+    const int slices = (e->C + 127) / 128;
+    hipLaunchKernelGGL(attn_pool_kernel, dim3(B, slices), dim3(256), (size_t)((L.W2 + 3) & ~3) * sizeof(float), st, pp);
+    MST_HIP_CHECK(hipGetLastError());
+    ProjParams pj{pooled, e->projfrag, e->proj_b, emb, B, e->C, e->cfg.embed_dim};
+    const int mt_all = (B + 15) / 16;
+    if (mt_all <= 1) launch_proj<1>(pj, 1, st);
+    else if (mt_all <= 2) launch_proj<2>(pj, 1, st);
+    else if (mt_all <= 3) launch_proj<3>(pj, 1, st);
+    else if (mt_all <= 5) launch_proj<5>(pj, 1, st);
+    else launch_proj<8>(pj, (B + 127) / 128, st);
+    MST_HIP_CHECK(hipGetLastError());
+  }
   return MST_OK;
 }
 

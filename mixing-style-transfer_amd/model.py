@@ -217,6 +217,32 @@ class HipEncoder:
             except Exception:
                 pass
 
+    def forward_train(self, logmel, feats):
+        """Train-mode forward in libmst.so (`mst_encoder_forward_train`): BatchNorm with batch statistics, Dropout as
+        identity.  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
+        1/sqrt(biased var + eps)).  Forward only -- the backward kernels are SURVEY 8 f1 work in progress."""
+        B, _, M, Fr = logmel.shape
+        L = _lib.lib()
+        need = L.mst_encoder_train_workspace_bytes(self._h, B, Fr)
+        if need == 0:
+            raise _lib.MstError("forward_train needs the default 20-mel sub-bands and frames >= 20")
+        if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need or self._ws_train.device != logmel.device:
+            self._ws_train = torch.empty(need, dtype=torch.uint8, device=logmel.device)
+        dev = logmel.device
+        emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=dev)
+        W1 = Fr // 5
+        out = {"film": torch.empty(B, self.n_sub * 192, device=dev),
+               "pool1": torch.empty(B, self.n_sub, 32, self.split // max(1, self.split // 10), W1, device=dev),
+               "pool_in": torch.empty(B, 64 * self.n_sub * self.freq_dim, W1 // 4, device=dev),
+               "bn1": torch.empty(self.n_sub, 32, 2, device=dev), "bn2": torch.empty(self.n_sub, 64, 2, device=dev)}
+        t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")])
+        with torch.cuda.device(dev):
+            _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(logmel.contiguous().float()), Fr,
+                                                   _lib.dptr(feats.contiguous().float()), B, _lib.dptr(emb), C.byref(t),
+                                                   _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+                       "mst_encoder_forward_train")
+        return emb, out
+
     def forward(self, logmel, feats, taps=False, events=None):
         """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
         B, _, M, Fr = logmel.shape

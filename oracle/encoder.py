@@ -33,7 +33,7 @@ def _f16_operand(t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 
 
 def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int,
-                taps=None, f16_operands=False) -> torch.Tensor:
+                taps=None, f16_operands=False, bn_training=False) -> torch.Tensor:
     """model.py:127-157 for sub-band i.  x (B, 8, split, F) -> (B, 64, H', W').
     f16_operands: the arithmetic of the opt-in "f16" precision mode (and of the reference under `--use_amp` autocast,
     src/train.py:251-253, for the convolutions): conv inputs and weights rounded to float16, products and sums in fp32."""
@@ -46,8 +46,13 @@ def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int
         if f16_operands:
             x, w = _f16_operand(x), _f16_operand(w, 1024.0)
         x = F.conv2d(x, w, sd[p + conv + ".bias"], padding=3)
-        x = F.batch_norm(x, sd[p + bn + ".running_mean"], sd[p + bn + ".running_var"],
-                         sd[p + bn + ".weight"], sd[p + bn + ".bias"], training=False, eps=1e-5)
+        if bn_training:   # nn.BatchNorm2d under model.train(): statistics of this batch, biased variance
+            if taps is not None:
+                taps[f"{bn}_{i}"] = (x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=False))
+            x = F.batch_norm(x, None, None, sd[p + bn + ".weight"], sd[p + bn + ".bias"], training=True, eps=1e-5)
+        else:
+            x = F.batch_norm(x, sd[p + bn + ".running_mean"], sd[p + bn + ".running_var"],
+                             sd[p + bn + ".weight"], sd[p + bn + ".bias"], training=False, eps=1e-5)
         x = g[:, :, None, None] * x + b[:, :, None, None]
         return F.max_pool2d(F.relu(x), pool)
 
@@ -71,11 +76,11 @@ def attention_pool(sd, x: torch.Tensor) -> torch.Tensor:
 
 
 def encoder_from_logmel(sd, lm: torch.Tensor, feats: torch.Tensor, split_size=20, overlap=10,
-                        taps=None, f16_operands=False) -> torch.Tensor:
+                        taps=None, f16_operands=False, bn_training=False) -> torch.Tensor:
     """log-mel (B, 8, M, F), features (B, Fd) -> embeddings (B, E).  model.py:290-382,508-542."""
     film = film_params(sd, feats)
     nsub = n_subbands(lm.shape[2], split_size, overlap)
-    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps, f16_operands)
+    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps, f16_operands, bn_training)
             for i in range(nsub)]
     cat = torch.cat(outs, dim=1)  # (B, nsub*64, H', W')
     flat = cat.reshape(cat.shape[0], cat.shape[1] * cat.shape[2], cat.shape[3])

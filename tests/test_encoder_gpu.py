@@ -204,6 +204,35 @@ def test_conv_f16_amp_mode_matches_its_own_definition():
     assert d < 2e-2
 
 
+@pytest.mark.parametrize("T,B", [(66150, 3), (44100 * 2 + 1234, 2)])
+def test_train_mode_forward_batch_statistics(T, B):
+    """SURVEY 8 f1 (first half): `mst_encoder_forward_train` == the oracle with BatchNorm in training mode (statistics of
+    the batch over (B, H, W), biased variance; dropout off): batch statistics, pool1, pool_in, embeddings."""
+    cfg = cases.CFG_DEFAULT
+    model, sd = build_model(cfg)
+    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(B, 64, generator=g) * 3.0
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        emb, t = model.hip_encoder().forward_train(lm, feats.cuda())
+        e_eval = model.hip_encoder().forward(lm, feats.cuda())
+    torch.cuda.synchronize()
+    taps = {}
+    want = oenc.encoder_from_logmel(sd, lm.cpu(), feats, cfg["split_size"], cfg["overlap"], taps, bn_training=True)
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    for i in (0, ns // 2, ns - 1):
+        for name, key in (("bn1", "bn1"), ("bn2", "bn2")):
+            mean, var = taps[f"{name}_{i}"]
+            got = t[key][i].cpu()
+            close(got[:, 0], mean, 1e-4)
+            close(1.0 / got[:, 1] ** 2 - 1e-5, var, 2e-4)
+        close(t["pool1"][:, i].cpu(), taps[f"pool1_{i}"])
+    close(t["pool_in"].cpu(), taps["pool_in"])
+    close(emb.cpu(), want)
+    assert (emb - e_eval).abs().max().item() > 1e-3 * e_eval.abs().max().item()   # it is NOT the eval forward
+
+
 def test_song_a_real_music_end_to_end():
     """BASELINE configs[0] on the GPU: real music through stage A + HIP encoder vs the reference goldens (bs=2)."""
     from test_melfeat_gpu import check_feats, check_logmel
