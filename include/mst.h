@@ -164,6 +164,18 @@ int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int f
                               float* emb, const mst_encoder_train_taps* taps, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Backward of max-pool / ReLU / FiLM / BatchNorm(batch statistics) of conv layer 1 or 2, from the activations that
+ * mst_encoder_forward_train left in `workspace` (same buffer, same B and frames).
+ * dpool: gradient of the pooled activation; element (clip, band, ch, r, c) at
+ *        dpool[clip*dp_clip + band*dp_band + ch*dp_ch + r*cols + c]   (layer 1: pool1 10 x W1; layer 2: pool_in 2 x W2).
+ * dy:    out, gradient of the convolution output, [n_sub][B][C][rows][cols] (per band a contiguous NCHW tensor: the
+ *        operand of the convolution weight / input gradient).
+ * dfilm: [B][n_sub*192], the layer's gamma / beta slots are ACCUMULATED (+=): zero it once per step.
+ * dbn:   out [n_sub][C][2] = (d BatchNorm weight, d BatchNorm bias).                                              */
+int mst_encoder_train_backward_apply(const mst_encoder* enc, int layer, int B, int frames, const float* dpool,
+                                     long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
+                                     float* dbn, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Augmentation chain.  Replaces AudioAugmenter.augment_stems src/mixing_utils.py:376-419 and
  * apply_spectral_tilt :421-433, apply_compression :435-447, apply_bandwidth_limit :449-456,

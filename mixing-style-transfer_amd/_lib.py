@@ -80,6 +80,9 @@ SYMBOLS = {
     "mst_encoder_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_backward_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
+                                                   C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_aug_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mst_aug_apply": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_size_t, C.c_void_p]),

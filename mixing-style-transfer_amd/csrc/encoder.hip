@@ -1301,6 +1301,172 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
   }
 }
 
+// ---- backward of everything between the raw convolution output y and the pooled activation:
+// max-pool -> ReLU -> FiLM -> BatchNorm(batch statistics), recomputed per lane from yraw.
+//   f = A y + C (A, C as in the forward), window max / arg-max (first maximum in row-major order, as PyTorch), ReLU;
+//   df = dpool at the arg-max if the max is positive;  dgamma_film += df z, dbeta_film += df  (z = BN output);
+//   dz = gamma_film df;  S1 = sum dz (= dbeta_bn),  S2 = sum dz zhat (= dgamma_bn)  over the batch;
+//   dy = gamma_bn / std * (dz - S1/N - zhat S2/N)   at every valid position (also where dz = 0).
+// Pass A (reduce) accumulates the sums, pass B (dx) writes dy as [band][B][COUT][rows][cols] (NCHW per band: the
+// operand layout of the convolution backward that consumes it).
+struct ApplyBwdParams {
+  const float* yraw;
+  const float2* aff;       // [B][nsub][COUT]
+  const float2* bnstat;    // [nsub][COUT] (mean, 1/std)
+  const float* bn_w;       // [nsub][COUT]
+  const float* bn_b;
+  const float* film;       // [B][nsub*192]
+  const float* dpool;      // upstream gradient of the pooled activation
+  long long dp_clip, dp_band, dp_ch;   // its strides (floats); rows are dp_cols apart
+  int dp_rows, dp_cols;
+  float* dfilm;            // [B][nsub*192]  (+=)
+  double* sums;            // [nsub][COUT][2] (+=)  S1, S2
+  float* dy;               // pass B
+  int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
+  double count;
+  int chunks;              // pass A: blocks per (clip, band)
+};
+
+template <int LAYER>
+__device__ __forceinline__ void unit_geometry(int tr, int tc, int g, int e, int& row, int& col) {
+  using C = CC<LAYER, 2>;
+  if constexpr (LAYER == 1) {
+    const int wv = e / C::WIN, pos = e % C::WIN;
+    row = C::TROWS * tr + pos / 5;
+    col = C::TCOLS * tc + 5 * (C::WPG * g + wv) + pos % 5;
+  } else {
+    row = 8 * tr + 4 * (g >> 1) + (e >> 2);
+    col = 8 * tc + 4 * (g & 1) + (e & 3);
+  }
+}
+
+// df for the NV values of one lane-unit: zero except at the arg-max of every pooling window with a positive maximum
+template <int LAYER>
+__device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v)[4 * CC<LAYER, 2>::MT], float2 ac, int clip,
+                                        int band, int ch, int tr, int tc, int g, float (&df)[4 * CC<LAYER, 2>::MT]) {
+  using C = CC<LAYER, 2>;
+  constexpr int NV = 4 * C::MT;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) df[e] = 0.f;
+  const float* dpb = p.dpool + clip * p.dp_clip + band * p.dp_band + ch * p.dp_ch;
+  constexpr int NW = LAYER == 1 ? C::WPG : 1, WIN = LAYER == 1 ? C::WIN : NV;
+#pragma unroll
+  for (int wv = 0; wv < NW; ++wv) {
+    float m = 0.f;
+    int am = -1;
+#pragma unroll
+    for (int pos = 0; pos < WIN; ++pos) {
+      const float f = fmaf(v[wv * WIN + pos], ac.x, ac.y);
+      if (f > m) m = f, am = wv * WIN + pos;
+    }
+    int pr, pc;
+    if constexpr (LAYER == 1) pr = tr, pc = 4 * C::WPG * tc + C::WPG * g + wv;
+    else pr = 2 * tr + (g >> 1), pc = 2 * tc + (g & 1);
+    const float d = (am >= 0 && pr < p.dp_rows && pc < p.dp_cols) ? dpb[(size_t)pr * p.dp_cols + pc] : 0.f;
+#pragma unroll
+    for (int e = 0; e < WIN; ++e) df[wv * WIN + e] = (wv * WIN + e == am) ? d : 0.f;
+  }
+}
+
+template <int LAYER>
+__global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdParams p) {   // grid (chunks, B*nsub)
+  using C = CC<LAYER, 2>;
+  constexpr int NT = C::NT, NV = 4 * C::MT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int clip = blockIdx.y / p.nsub, band = blockIdx.y % p.nsub;
+  const int wus = p.tiles_r * p.tiles_c * NT;                 // wave-units of this (clip, band)
+  const int per = ((wus + p.chunks - 1) / p.chunks + 3) & ~3;  // multiple of 4: a wave keeps its N-tile
+  const int w0 = blockIdx.x * per, w1 = min(wus, w0 + per);
+  const int j = lane & 15, g = lane >> 4;
+  float dgam = 0.f, dbet = 0.f;
+  double s1 = 0.0, s2 = 0.0;
+  int ch = 0;
+  for (int wu = w0 + wave; wu < w1; wu += 4) {
+    const int n = wu % NT, tile = wu / NT, tc = tile % p.tiles_c, tr = tile / p.tiles_c;
+    ch = n * 16 + j;
+    const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
+    const float2 ms = p.bnstat[band * C::COUT + ch];
+    const float gb = p.bn_w[band * C::COUT + ch], bb = p.bn_b[band * C::COUT + ch];
+    const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
+    const size_t u = ((((size_t)clip * p.nsub + band) * p.tiles_r + tr) * p.tiles_c + tc) * NT + n;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (u * 64 + lane) * NV);
+    float v[NV], df[NV];
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+      const f32x4 q = src[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
+    }
+    unit_df<LAYER>(p, v, ac, clip, band, ch, tr, tc, g, df);
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const float zh = (v[e] - ms.x) * ms.y;
+      dgam = fmaf(df[e], fmaf(gb, zh, bb), dgam);
+      dbet += df[e];
+      const double dz = (double)gf * (double)df[e];
+      s1 += dz, s2 += dz * (double)zh;
+    }
+  }
+  // lanes j, j+16, j+32, j+48 share the channel
+  dgam += __shfl_xor(dgam, 16, 64), dgam += __shfl_xor(dgam, 32, 64);
+  dbet += __shfl_xor(dbet, 16, 64), dbet += __shfl_xor(dbet, 32, 64);
+  s1 += __shfl_xor(s1, 16, 64), s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 16, 64), s2 += __shfl_xor(s2, 32, 64);
+  if (lane < 16 && w0 + wave < w1) {
+    float* fl = p.dfilm + ((size_t)clip * p.nsub + band) * 192;
+    atomicAdd(fl + p.goff + ch, dgam);
+    atomicAdd(fl + p.boff + ch, dbet);
+    atomicAdd(p.sums + ((size_t)band * C::COUT + ch) * 2, s1);
+    atomicAdd(p.sums + ((size_t)band * C::COUT + ch) * 2 + 1, s2);
+  }
+}
+
+template <int LAYER>
+__global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams p, long long units) {
+  using C = CC<LAYER, 2>;
+  constexpr int NT = C::NT, NV = 4 * C::MT;
+  const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (u >= units) return;
+  const int lane = (int)(u & 63), n = (int)((u >> 6) % NT);
+  long long tile = (u >> 6) / NT;
+  const int tc = (int)(tile % p.tiles_c);
+  tile /= p.tiles_c;
+  const int tr = (int)(tile % p.tiles_r);
+  tile /= p.tiles_r;
+  const int band = (int)(tile % p.nsub), clip = (int)(tile / p.nsub);
+  const int j = lane & 15, g = lane >> 4, ch = n * 16 + j;
+  const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
+  const float2 ms = p.bnstat[band * C::COUT + ch];
+  const float gb = p.bn_w[band * C::COUT + ch];
+  const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
+  const double m1 = p.sums[((size_t)band * C::COUT + ch) * 2] / p.count, m2 = p.sums[((size_t)band * C::COUT + ch) * 2 + 1] / p.count;
+  const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (size_t)u * NV);
+  float v[NV], df[NV];
+#pragma unroll
+  for (int t = 0; t < C::MT; ++t) {
+    const f32x4 q = src[t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
+  }
+  unit_df<LAYER>(p, v, ac, clip, band, ch, tr, tc, g, df);
+  float* dyb = p.dy + (((size_t)band * p.B + clip) * C::COUT + ch) * (size_t)p.rows * p.cols;
+  const float k = gb * ms.y;
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    int row, col;
+    unit_geometry<LAYER>(tr, tc, g, e, row, col);
+    if (row < p.rows && col < p.cols) {
+      const float zh = (v[e] - ms.x) * ms.y;
+      dyb[(size_t)row * p.cols + col] = k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2);
+    }
+  }
+}
+
+__global__ void sums_to_dbn_kernel(const double* sums, float* dbn, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dbn[2 * i] = (float)sums[2 * i + 1], dbn[2 * i + 1] = (float)sums[2 * i];
+}
+
 template <int LAYER, int SUB>
 hipError_t launch_conv(const ConvParams& cp, int grid, hipStream_t st) {
   using GEO = ConvGeom<LAYER, SUB>;
@@ -1647,7 +1813,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
   const int ns = e->cfg.n_subbands;
-  float* film = (taps && taps->film) ? taps->film : reinterpret_cast<float*>(ws + L.film);
+  float* film = reinterpret_cast<float*>(ws + L.film);   // kept in the workspace: the backward pass reads it
   float* pool1 = (taps && taps->pool1) ? taps->pool1 : reinterpret_cast<float*>(ws + L.pool1);
   float* pool_in = (taps && taps->pool_in) ? taps->pool_in : reinterpret_cast<float*>(ws + L.pool_in);
   float2* aff1 = reinterpret_cast<float2*>(ws + L.aff1);
@@ -1693,7 +1859,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     }
     hipLaunchKernelGGL((conv1_resident_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     MST_HIP_CHECK(hipGetLastError());
-    float2* bnstat = (taps && taps->bn1) ? reinterpret_cast<float2*>(taps->bn1) : reinterpret_cast<float2*>(ws + T.bn1);
+    float2* bnstat = reinterpret_cast<float2*>(ws + T.bn1);
     FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, (double)B * e->cfg.split_size * frames, e->cfg.bn_eps,
                   ns, 32, 0, 32};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
@@ -1724,7 +1890,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     }
     hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     MST_HIP_CHECK(hipGetLastError());
-    float2* bnstat = (taps && taps->bn2) ? reinterpret_cast<float2*>(taps->bn2) : reinterpret_cast<float2*>(ws + T.bn2);
+    float2* bnstat = reinterpret_cast<float2*>(ws + T.bn2);
     FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
     ApplyParams ap{y2, aff2, pool_in, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
@@ -1750,6 +1916,60 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     else launch_proj<8>(pj, (B + 127) / 128, st);
     MST_HIP_CHECK(hipGetLastError());
   }
+  if (taps && taps->film) MST_HIP_CHECK(hipMemcpyAsync(taps->film, film, (size_t)B * ns * 192 * 4, hipMemcpyDeviceToDevice, st));
+  if (taps && taps->bn1) MST_HIP_CHECK(hipMemcpyAsync(taps->bn1, ws + T.bn1, (size_t)ns * 32 * 8, hipMemcpyDeviceToDevice, st));
+  if (taps && taps->bn2) MST_HIP_CHECK(hipMemcpyAsync(taps->bn2, ws + T.bn2, (size_t)ns * 64 * 8, hipMemcpyDeviceToDevice, st));
+  return MST_OK;
+}
+
+int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int frames, const float* dpool,
+                                     long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
+                                     float* dbn, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && dpool && dy && dfilm && dbn, "mst_encoder_train_backward_apply: NULL argument");
+  MST_REQUIRE(e->sub == 2 && (layer == 1 || layer == 2) && B > 0 && frames >= 20, "mst_encoder_train_backward_apply: bad arguments");
+  const TrainLayout T = train_layout(e, B, frames);
+  const WsLayout& L = T.base;
+  if (!workspace || workspace_bytes < T.total)
+    return mst::fail(MST_ENOMEM, "mst_encoder_train_backward_apply: workspace %zu B < required %zu B", workspace_bytes, T.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int ns = e->cfg.n_subbands;
+  ApplyBwdParams p{};
+  p.film = reinterpret_cast<const float*>(ws + L.film);
+  p.dpool = dpool, p.dp_clip = dp_clip, p.dp_band = dp_band, p.dp_ch = dp_ch;
+  p.dfilm = dfilm, p.dy = dy, p.B = B, p.nsub = ns;
+  const int cout = layer == 1 ? 32 : 64;
+  double* sums = reinterpret_cast<double*>(ws + (layer == 1 ? T.stats1 : T.stats2));   // forward sums are spent: reuse
+  p.sums = sums;
+  MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * 8, st));
+  if (layer == 1) {
+    p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
+    p.bnstat = reinterpret_cast<const float2*>(ws + T.bn1), p.bn_w = e->bn1w, p.bn_b = e->bn1b;
+    p.dp_rows = e->H1, p.dp_cols = L.W1, p.tiles_r = T.tr1, p.tiles_c = T.tc1;
+    p.rows = e->cfg.split_size, p.cols = frames, p.goff = 0, p.boff = 32;
+    p.count = (double)B * e->cfg.split_size * frames;
+  } else {
+    p.yraw = reinterpret_cast<const float*>(ws + T.y2), p.aff = reinterpret_cast<const float2*>(ws + L.aff2);
+    p.bnstat = reinterpret_cast<const float2*>(ws + T.bn2), p.bn_w = e->bn2w, p.bn_b = e->bn2b;
+    p.dp_rows = e->FD, p.dp_cols = L.W2, p.tiles_r = T.tr2, p.tiles_c = T.tc2;
+    p.rows = e->H1, p.cols = L.W1, p.goff = 64, p.boff = 128;
+    p.count = (double)B * e->H1 * L.W1;
+  }
+  const int nt = layer == 1 ? 2 : 4;
+  const int wus = p.tiles_r * p.tiles_c * nt;
+  p.chunks = std::max(1, std::min(16, wus / 64));
+  const long long units = (long long)B * ns * wus * 64;
+  if (layer == 1) {
+    hipLaunchKernelGGL((apply_bwd_reduce_kernel<1>), dim3(p.chunks, B * ns), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((apply_bwd_dx_kernel<1>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, p, units);
+  } else {
+    hipLaunchKernelGGL((apply_bwd_reduce_kernel<2>), dim3(p.chunks, B * ns), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((apply_bwd_dx_kernel<2>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, p, units);
+  }
+  MST_HIP_CHECK(hipGetLastError());
+  // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
+  hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout);
+  MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
 

@@ -243,6 +243,34 @@ class HipEncoder:
                        "mst_encoder_forward_train")
         return emb, out
 
+    def backward_apply(self, layer, dpool, dfilm, B, frames):
+        """Backward of pool/ReLU/FiLM/BatchNorm(train) of conv layer 1 or 2 from the activations the last
+        `forward_train` call left in its workspace (`mst_encoder_train_backward_apply`).
+        dpool: layer 1 (B, n_sub, 32, 10, W1) or any tensor with those dims and arbitrary clip / band / channel
+        strides; layer 2 (B, 64*n_sub*freq_dim, W2) = d pool_in.  dfilm (B, n_sub*192) is accumulated in place.
+        Returns (dy (n_sub, B, C, rows, cols), dbn (n_sub, C, 2) = (d weight, d bias))."""
+        L = _lib.lib()
+        dev = dpool.device
+        W1 = frames // 5
+        if layer == 1:
+            assert dpool.dim() == 5 and dpool.stride(4) == 1 and dpool.stride(3) == W1
+            st = (dpool.stride(0), dpool.stride(1), dpool.stride(2))
+            dy = torch.empty(self.n_sub, B, 32, self.split, frames, device=dev)
+            dbn = torch.empty(self.n_sub, 32, 2, device=dev)
+        else:
+            dpool = dpool.contiguous()
+            W2 = W1 // 4
+            st = (dpool.shape[1] * W2, 64 * self.freq_dim * W2, self.freq_dim * W2)
+            dy = torch.empty(self.n_sub, B, 64, self.split // 2, W1, device=dev)
+            dbn = torch.empty(self.n_sub, 64, 2, device=dev)
+        need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
+        with torch.cuda.device(dev):
+            _lib.check(L.mst_encoder_train_backward_apply(self._h, layer, B, frames, _lib.dptr(dpool), st[0], st[1], st[2],
+                                                          _lib.dptr(dy), _lib.dptr(dfilm), _lib.dptr(dbn),
+                                                          _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+                       "mst_encoder_train_backward_apply")
+        return dy, dbn
+
     def forward(self, logmel, feats, taps=False, events=None):
         """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
         B, _, M, Fr = logmel.shape

@@ -46,6 +46,9 @@ def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int
         if f16_operands:
             x, w = _f16_operand(x), _f16_operand(w, 1024.0)
         x = F.conv2d(x, w, sd[p + conv + ".bias"], padding=3)
+        if taps is not None and x.requires_grad:   # gradient checks: keep the convolution output and its gradient
+            x.retain_grad()
+            taps[f"{conv}_out_{i}"] = x
         if bn_training:   # nn.BatchNorm2d under model.train(): statistics of this batch, biased variance
             if taps is not None:
                 taps[f"{bn}_{i}"] = (x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=False))

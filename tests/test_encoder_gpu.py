@@ -233,6 +233,54 @@ def test_train_mode_forward_batch_statistics(T, B):
     assert (emb - e_eval).abs().max().item() > 1e-3 * e_eval.abs().max().item()   # it is NOT the eval forward
 
 
+def test_train_mode_backward_of_pool_relu_film_batchnorm():
+    """`mst_encoder_train_backward_apply` (max-pool -> ReLU -> FiLM -> BatchNorm with batch statistics, both
+    layers) against torch autograd through the oracle: gradient of the convolution outputs, of the FiLM parameters and
+    of the BatchNorm weight / bias.  The convolution input gradient between the layers comes from autograd here."""
+    cfg = cases.CFG_DEFAULT
+    model, sd = build_model(cfg)
+    B, T = 2, 66150
+    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
+    g = torch.Generator().manual_seed(6)
+    feats = torch.randn(B, 64, generator=g) * 3.0
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        enc = model.hip_encoder()
+        emb, t = enc.forward_train(lm, feats.cuda())
+    frames = lm.shape[-1]
+    # oracle with autograd: leaf = FiLM parameters and the BN affine parameters
+    sdg = {k: v.clone() for k, v in sd.items()}
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    for i in range(ns):
+        for k in ("bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias", "conv1.weight", "conv2.weight"):
+            sdg[f"audio_encoder.subnet_cnns.{i}.{k}"].requires_grad_(True)
+    film = oenc.film_params(sd, feats).clone().requires_grad_(True)
+    taps = {}
+    lmc = lm.cpu()
+    outs = [oenc.subband_cnn(sdg, i, lmc[:, :, i * 10:i * 10 + 20, :], film, 20, taps, bn_training=True) for i in range(ns)]
+    cat = torch.cat(outs, dim=1)
+    pool_in = cat.reshape(B, cat.shape[1] * cat.shape[2], cat.shape[3])
+    for i in range(ns):
+        taps[f"pool1_{i}"].retain_grad()
+    R = torch.randn(pool_in.shape, generator=g)
+    (pool_in * R).sum().backward()
+    # native: layer 2 from d pool_in = R, layer 1 from autograd's d pool1
+    dfilm = torch.zeros(B, ns * 192, device="cuda")
+    dy2, dbn2 = enc.backward_apply(2, R.cuda(), dfilm, B, frames)
+    dp1 = torch.stack([taps[f"pool1_{i}"].grad for i in range(ns)], 1).cuda()       # (B, ns, 32, 10, W1)
+    dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, frames)
+    torch.cuda.synchronize()
+    for i in (0, ns // 2, ns - 1):
+        close(dy2[i].cpu(), taps[f"conv2_out_{i}"].grad, 2e-4)
+        close(dy1[i].cpu(), taps[f"conv1_out_{i}"].grad, 2e-4)
+        pfx = f"audio_encoder.subnet_cnns.{i}."
+        close(dbn2[i, :, 0].cpu(), sdg[pfx + "bn2.weight"].grad, 2e-4)
+        close(dbn2[i, :, 1].cpu(), sdg[pfx + "bn2.bias"].grad, 2e-4)
+        close(dbn1[i, :, 0].cpu(), sdg[pfx + "bn1.weight"].grad, 2e-4)
+        close(dbn1[i, :, 1].cpu(), sdg[pfx + "bn1.bias"].grad, 2e-4)
+    close(dfilm.cpu(), film.grad, 2e-4)
+
+
 def test_song_a_real_music_end_to_end():
     """BASELINE configs[0] on the GPU: real music through stage A + HIP encoder vs the reference goldens (bs=2)."""
     from test_melfeat_gpu import check_feats, check_logmel
