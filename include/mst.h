@@ -158,11 +158,24 @@ typedef struct mst_encoder_train_taps {
   float* pool_in;
   float* bn1;
   float* bn2;
+  const float* film_in; /* optional INPUT dev [B][n_sub*192]: FiLM parameters from the caller's own MLP (then feats may
+                           be NULL); emb may be NULL as well: stop at pool_in, the caller runs its own pooling head */
+  const unsigned char* drop1_mask; /* optional INPUT dev, layout of pool1: Dropout keep-mask after the first pooling
+                                      (src/model.py:118: Dropout(0.3)); pool1 = mask ? pooled * drop1_scale : 0 */
+  float drop1_scale;               /* 1 / (1 - p) */
 } mst_encoder_train_taps;
 size_t mst_encoder_train_workspace_bytes(const mst_encoder* enc, int B, int frames);
 int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int frames, const float* feats, int B,
                               float* emb, const mst_encoder_train_taps* taps, void* workspace,
                               size_t workspace_bytes, void* stream);
+
+/* Refresh the convolution / BatchNorm parameters of the TRAINING kernels from device tensors (concatenated over the
+ * sub-bands, reference state_dict shapes) -- once per optimizer step; re-swizzles the MFMA weight fragments on the
+ * device.  The eval-mode constants (folded running statistics, f16 fragments) are NOT refreshed: create a new
+ * encoder for evaluation after training.                                                                         */
+int mst_encoder_update_trunk_params(mst_encoder* enc, const float* conv1_w, const float* conv1_b, const float* bn1_w,
+                                    const float* bn1_b, const float* conv2_w, const float* conv2_b,
+                                    const float* bn2_w, const float* bn2_b, void* stream);
 
 /* Backward of max-pool / ReLU / FiLM / BatchNorm(batch statistics) of conv layer 1 or 2, from the activations that
  * mst_encoder_forward_train left in `workspace` (same buffer, same B and frames).

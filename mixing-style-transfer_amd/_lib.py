@@ -41,7 +41,7 @@ class EncoderTaps(C.Structure):
 
 class EncoderTrainTaps(C.Structure):
     _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("bn1", C.c_void_p),
-                ("bn2", C.c_void_p)]
+                ("bn2", C.c_void_p), ("film_in", C.c_void_p), ("drop1_mask", C.c_void_p), ("drop1_scale", C.c_float)]
 
 
 class AugStem(C.Structure):
@@ -83,6 +83,7 @@ SYMBOLS = {
     "mst_encoder_train_backward_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                                    C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_update_trunk_params": (C.c_int, [C.c_void_p] * 10),
     "mst_aug_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mst_aug_apply": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_size_t, C.c_void_p]),

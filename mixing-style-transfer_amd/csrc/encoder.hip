@@ -1254,6 +1254,8 @@ struct ApplyParams {
   const float* yraw;
   const float2* aff;
   float* out;
+  const unsigned char* mask;   // optional Dropout keep-mask over the pooled output (layer 1), same layout as `out`
+  float mask_scale;            // 1 / (1 - p)
   int B, nsub, tiles_r, tiles_c, out_rows, out_cols;
   long long units;   // B * nsub * tiles_r * tiles_c * NT * 64
 };
@@ -1288,8 +1290,10 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
 #pragma unroll
       for (int pos = 0; pos < C::WIN; ++pos) m = fmaxf(m, fmaf(v[wv * C::WIN + pos], ac.x, ac.y));
       const int pc = 4 * C::WPG * tc + C::WPG * g + wv;
-      if (pc < p.out_cols)
-        p.out[((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + tr) * p.out_cols + pc] = m;
+      if (pc < p.out_cols) {
+        const size_t o = ((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + tr) * p.out_cols + pc;
+        p.out[o] = p.mask ? (p.mask[o] ? m * p.mask_scale : 0.f) : m;
+      }
     }
   } else {
     float m = 0.f;
@@ -1465,6 +1469,23 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
 __global__ void sums_to_dbn_kernel(const double* sums, float* dbn, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dbn[2 * i] = (float)sums[2 * i + 1], dbn[2 * i + 1] = (float)sums[2 * i];
+}
+
+// conv weights [nsub][COUT][CIN][49] (device) -> MFMA B-fragment chunks, same layout as conv_fragments() builds on the host
+__global__ void conv_fragments_kernel(const float* w, float* f, int nsub, int cout, int cin, int wchp) {
+  const int nt = cout / 16, nch = cin / 4;
+  const long long total = (long long)nsub * nch * 49 * nt * 64;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  long long r = i >> 6;
+  const int n = (int)(r % nt);
+  r /= nt;
+  const int tap = (int)(r % 49);
+  r /= 49;
+  const int ch = (int)(r % nch), b = (int)(r / nch);
+  const int co = n * 16 + (lane & 15), ci = 4 * ch + (lane >> 4);
+  f[((size_t)b * nch + ch) * wchp + ((size_t)tap * nt + n) * 64 + lane] = w[(((size_t)b * cout + co) * cin + ci) * 49 + tap];
 }
 
 template <int LAYER, int SUB>
@@ -1802,7 +1823,7 @@ size_t mst_encoder_train_workspace_bytes(const mst_encoder* e, int B, int frames
 
 int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
                               const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(e && logmel && feats && emb, "mst_encoder_forward_train: NULL argument");
+  MST_REQUIRE(e && logmel && (feats || (taps && taps->film_in)), "mst_encoder_forward_train: NULL argument");
   MST_REQUIRE(e->sub == 2, "mst_encoder_forward_train: needs the default 20-mel sub-bands (pool height 2)");
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward_train: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
   const TrainLayout T = train_layout(e, B, frames);
@@ -1825,7 +1846,9 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   double* stats2 = reinterpret_cast<double*>(ws + T.stats2);
   MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * 8, st));
   MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * 8, st));
-  {   // FiLM MLP (its eval-mode affines are overwritten by bn_fold_kernel below)
+  if (taps && taps->film_in) {   // FiLM parameters computed by the caller (its MLP keeps its autograd graph)
+    MST_HIP_CHECK(hipMemcpyAsync(film, taps->film_in, (size_t)B * ns * 192 * 4, hipMemcpyDeviceToDevice, st));
+  } else {   // FiLM MLP (its eval-mode affines are overwritten by bn_fold_kernel below)
     FilmParams fp{feats, e->w0t, e->b0, e->w3t, e->b3, e->hwt, e->hb, e->s1, e->t1, e->s2, e->t2,
                   film, aff1, aff2, e->cfg.feature_dim, e->cfg.film_hidden, ns};
     const int groups = ns < 4 ? ns : 4;
@@ -1863,7 +1886,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, (double)B * e->cfg.split_size * frames, e->cfg.bn_eps,
                   ns, 32, 0, 32};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
-    ApplyParams ap{y1, aff1, pool1, B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64};
+    ApplyParams ap{y1, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
+                   B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64};
     hipLaunchKernelGGL((apply_kernel<1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -1893,11 +1917,11 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn2);
     FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
-    ApplyParams ap{y2, aff2, pool_in, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
+    ApplyParams ap{y2, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
     hipLaunchKernelGGL((apply_kernel<2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
-  {
+  if (emb) {   // attention pooling head (emb == NULL: the caller runs its own head on pool_in)
     AttnParams ap{pool_in, e->att0frag, e->att0_b, e->att2_w, e->att2_b, scores, B, e->C, L.W2, e->cfg.attn_hidden};
     const int mtiles = (B * L.W2 + 15) / 16;
     hipLaunchKernelGGL(attn_scores_kernel, dim3(mtiles), dim3(256), 0, st, ap);
@@ -1970,6 +1994,28 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
   hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout);
   MST_HIP_CHECK(hipGetLastError());
+  return MST_OK;
+}
+
+int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const float* conv1_b, const float* bn1_w,
+                                    const float* bn1_b, const float* conv2_w, const float* conv2_b, const float* bn2_w,
+                                    const float* bn2_b, void* stream) {
+  MST_REQUIRE(e && conv1_w && conv1_b && bn1_w && bn1_b && conv2_w && conv2_b && bn2_w && bn2_b,
+              "mst_encoder_update_trunk_params: NULL argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ns = e->cfg.n_subbands;
+  {
+    const long long t1 = (long long)ns * 2 * 49 * 2 * 64, t2 = (long long)ns * 8 * 49 * 4 * 64;
+    hipLaunchKernelGGL(conv_fragments_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, conv1_w, e->w1frag, ns, 32, 8,
+                       ConvGeom<1, 2>::WBP);
+    hipLaunchKernelGGL(conv_fragments_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, st, conv2_w, e->w2frag, ns, 64, 32,
+                       ConvGeom<2, 2>::WBP);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  const struct { float* dst; const float* src; int n; } cp[] = {
+      {e->c1b, conv1_b, ns * 32}, {e->bn1w, bn1_w, ns * 32}, {e->bn1b, bn1_b, ns * 32},
+      {e->c2b, conv2_b, ns * 64}, {e->bn2w, bn2_w, ns * 64}, {e->bn2b, bn2_b, ns * 64}};
+  for (const auto& c : cp) MST_HIP_CHECK(hipMemcpyAsync(c.dst, c.src, (size_t)c.n * 4, hipMemcpyDeviceToDevice, st));
   return MST_OK;
 }
 

@@ -207,7 +207,7 @@ class HipEncoder:
         _lib.check(_lib.lib().mst_encoder_set_precision(h, self.mode), "mst_encoder_set_precision")
         self._ws = None
         self.embed_dim = ae.attention_pooling.output_dim
-        self.n_sub, self.split, self.freq_dim = ae.n_subbands, ae.split_size, ae.freq_dim
+        self.n_sub, self.split, self.freq_dim, self.overlap = ae.n_subbands, ae.split_size, ae.freq_dim, ae.overlap
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -217,10 +217,12 @@ class HipEncoder:
             except Exception:
                 pass
 
-    def forward_train(self, logmel, feats):
-        """Train-mode forward in libmst.so (`mst_encoder_forward_train`): BatchNorm with batch statistics, Dropout as
-        identity.  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
-        1/sqrt(biased var + eps)).  Forward only -- the backward kernels are SURVEY 8 f1 work in progress."""
+    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0):
+        """Train-mode forward in libmst.so (`mst_encoder_forward_train`): BatchNorm with batch statistics.
+        feats (B, Fd): FiLM MLP in HIP; or film (B, n_sub*192): FiLM parameters from the caller's own MLP.
+        head=False stops at pool_in (emb is None).  drop1_mask: uint8 keep-mask shaped like pool1 (Dropout after the
+        first pooling).  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
+        1/sqrt(biased var + eps)).  The raw conv outputs stay in the workspace for `backward_apply`."""
         B, _, M, Fr = logmel.shape
         L = _lib.lib()
         need = L.mst_encoder_train_workspace_bytes(self._h, B, Fr)
@@ -229,19 +231,33 @@ class HipEncoder:
         if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need or self._ws_train.device != logmel.device:
             self._ws_train = torch.empty(need, dtype=torch.uint8, device=logmel.device)
         dev = logmel.device
-        emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=dev)
+        emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=dev) if head else None
         W1 = Fr // 5
         out = {"film": torch.empty(B, self.n_sub * 192, device=dev),
                "pool1": torch.empty(B, self.n_sub, 32, self.split // max(1, self.split // 10), W1, device=dev),
                "pool_in": torch.empty(B, 64 * self.n_sub * self.freq_dim, W1 // 4, device=dev),
                "bn1": torch.empty(self.n_sub, 32, 2, device=dev), "bn2": torch.empty(self.n_sub, 64, 2, device=dev)}
-        t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")])
+        film_c = film.detach().contiguous().float() if film is not None else None
+        feats_c = feats.contiguous().float() if feats is not None else None
+        mask_c = drop1_mask.contiguous() if drop1_mask is not None else None
+        if mask_c is not None:
+            assert mask_c.dtype == torch.uint8 and tuple(mask_c.shape) == tuple(out["pool1"].shape)
+        t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")],
+                                  _lib.dptr(film_c), _lib.dptr(mask_c), 1.0 / (1.0 - drop1_p) if mask_c is not None else 1.0)
+        lm = logmel.contiguous().float()
         with torch.cuda.device(dev):
-            _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(logmel.contiguous().float()), Fr,
-                                                   _lib.dptr(feats.contiguous().float()), B, _lib.dptr(emb), C.byref(t),
-                                                   _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+            _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(lm), Fr, _lib.dptr(feats_c), B, _lib.dptr(emb),
+                                                   C.byref(t), _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
                        "mst_encoder_forward_train")
         return emb, out
+
+    def update_trunk_params(self, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b):
+        """Refresh the training kernels' conv / BatchNorm parameters from device tensors stacked over the sub-bands."""
+        ts = [t.detach().contiguous().float() for t in (c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)]
+        with torch.cuda.device(ts[0].device):
+            _lib.check(_lib.lib().mst_encoder_update_trunk_params(self._h, *[_lib.dptr(t) for t in ts],
+                                                                  _lib.stream_ptr(ts[0].device)),
+                       "mst_encoder_update_trunk_params")
 
     def backward_apply(self, layer, dpool, dfilm, B, frames):
         """Backward of pool/ReLU/FiLM/BatchNorm(train) of conv layer 1 or 2 from the activations the last
@@ -306,6 +322,53 @@ class HipEncoder:
         return (emb, out) if taps else emb
 
 
+class _HipTrunk(torch.autograd.Function):
+    """The 11 x [conv -> BatchNorm(batch statistics) -> FiLM -> ReLU -> max-pool] x 2 trunk for training.
+    Forward: libmst.so (`mst_encoder_forward_train`, raw conv outputs kept).  Backward: pool / ReLU / FiLM / BatchNorm in
+    libmst.so (`mst_encoder_train_backward_apply`); the convolution weight / input gradients are still taken from
+    PyTorch-ROCm (`aten.convolution_backward`, MIOpen) per sub-band -- the hand-written wgrad / dgrad kernels are the
+    remaining piece of SURVEY 8 f1."""
+
+    @staticmethod
+    def forward(ctx, enc, logmel, film, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b, drop_p):
+        B, _, M, Fr = logmel.shape
+        enc.update_trunk_params(c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)
+        W1 = Fr // 5
+        mask = None
+        if drop_p > 0.0:
+            mask = (torch.rand(B, enc.n_sub, 32, enc.split // 2, W1, device=logmel.device) >= drop_p).to(torch.uint8)
+        _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p)
+        ctx.enc, ctx.drop_p, ctx.dims = enc, drop_p, (B, Fr)
+        ctx.save_for_backward(logmel, t["pool1"], c1w, c2w, mask)
+        ctx.mark_non_differentiable(t["bn1"], t["bn2"])
+        return t["pool_in"], t["bn1"], t["bn2"]
+
+    @staticmethod
+    def backward(ctx, dpool_in, _d1, _d2):
+        enc, (B, Fr) = ctx.enc, ctx.dims
+        logmel, p1, c1w, c2w, mask = ctx.saved_tensors
+        ns, ov, sp = enc.n_sub, enc.overlap, enc.split
+        bw = torch.ops.aten.convolution_backward
+        dfilm = torch.zeros(B, ns * 192, device=logmel.device)
+        dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr)
+        gi, gw2, gb2 = [], [], []
+        for i in range(ns):
+            a, b, c = bw(dy2[i], p1[:, i].contiguous(), c2w[i], [64], [1, 1], [3, 3], [1, 1], False, [0, 0], 1,
+                         [True, True, True])
+            gi.append(a), gw2.append(b), gb2.append(c)
+        dp1 = torch.stack(gi, 1)
+        if mask is not None:
+            dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
+        dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
+        gw1, gb1 = [], []
+        for i in range(ns):
+            _, b, c = bw(dy1[i], logmel[:, :, i * ov:i * ov + sp, :].contiguous(), c1w[i], [32], [1, 1], [3, 3], [1, 1],
+                         False, [0, 0], 1, [False, True, True])
+            gw1.append(b), gb1.append(c)
+        return (None, None, dfilm, torch.stack(gw1), torch.stack(gb1), dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(),
+                torch.stack(gw2), torch.stack(gb2), dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous(), None)
+
+
 class MixingStyleEncoder(nn.Module):
     """reference src/model.py:467-542.  `encoder_backend`: "hip" (default; eval/no-grad forward in libmst.so) or
     "torch" (PyTorch-ROCm ops for stage B; stage A stays HIP) -- BASELINE.json configs[2] vs configs[1]."""
@@ -320,6 +383,10 @@ class MixingStyleEncoder(nn.Module):
         self.conv1_precision = "fp32"   # "f16x3": opt-in split-precision f16 MFMA for conv1 (see include/mst.h)
         self._hip = None
         self._hip_version = None
+        self._hip_train = None
+        # training (grad enabled, model.train()): "hip" = conv trunk forward + pool/ReLU/FiLM/BatchNorm backward in libmst.so
+        # (see _HipTrunk; 52 ms vs 98 ms per 72-clip step); "torch" = everything on PyTorch-ROCm autograd
+        self.train_backend = "hip"
 
     def _params_version(self):
         return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
@@ -334,7 +401,37 @@ class MixingStyleEncoder(nn.Module):
         return torch.is_grad_enabled() and (self.training or mixing_features.requires_grad) and \
             any(p.requires_grad for p in self.parameters())
 
+    def _forward_train_hip(self, logmel, mixing_features):
+        """Training forward with the trunk in libmst.so (see _HipTrunk); FiLM MLP and attention head stay torch modules."""
+        ae, fe = self.audio_encoder, self.film_encoder
+        if self._hip_train is None:
+            self._hip_train = HipEncoder(self, "fp32")
+        enc = self._hip_train
+        cn = ae.subnet_cnns
+        st = lambda f: torch.stack([f(c) for c in cn])  # noqa: E731
+        flat = fe.film_head(fe.feature_mlp(mixing_features))
+        p = cn[0].dropout1.p if self.training else 0.0
+        pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, st(lambda c: c.conv1.weight), st(lambda c: c.conv1.bias),
+                                            st(lambda c: c.bn1.weight), st(lambda c: c.bn1.bias),
+                                            st(lambda c: c.conv2.weight), st(lambda c: c.conv2.bias),
+                                            st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias), float(p))
+        with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
+            B, Fr = logmel.shape[0], logmel.shape[-1]
+            for stat, name, n in ((bn1, "bn1", B * ae.split_size * Fr), (bn2, "bn2", B * (ae.split_size // 2) * (Fr // 5))):
+                mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * (n / max(n - 1, 1))
+                for i, c in enumerate(cn):
+                    bn = getattr(c, name)
+                    m = bn.momentum if bn.momentum is not None else 0.1
+                    bn.running_mean.mul_(1 - m).add_(mean[i], alpha=m)
+                    bn.running_var.mul_(1 - m).add_(var[i], alpha=m)
+                    bn.num_batches_tracked += 1
+        x = F.dropout(pool_in, cn[0].dropout2.p, self.training)
+        return ae.attention_pooling(x)
+
     def forward_from_logmel(self, logmel, mixing_features):
+        if self.encoder_backend == "hip" and self.training and self.train_backend == "hip" and \
+                self._needs_autograd(mixing_features) and self.audio_encoder.split_size // 10 == 2:
+            return self._forward_train_hip(logmel, mixing_features)
         if self.encoder_backend == "hip" and not self._needs_autograd(mixing_features):
             if self.training:
                 raise RuntimeError("HIP encoder forward implements eval-mode BatchNorm/Dropout; call model.eval() "

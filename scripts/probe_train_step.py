@@ -1,5 +1,5 @@
-"""Train-step timing of the CURRENT training path (stage A + loss in HIP, encoder fwd/bwd on PyTorch-ROCm/MIOpen):
-the number a native backward has to beat.  Run on the GPU box."""
+"""Train-step timing (stage A + loss in HIP; encoder: TRAIN_BACKEND=hip (default: native trunk forward and
+pool/ReLU/FiLM/BN backward, conv gradients via MIOpen) or TRAIN_BACKEND=torch (all PyTorch-ROCm)).  Run on the GPU box."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,7 @@ from mst_amd.synth import synth_batch
 B, T = int(os.environ.get("B", 72)), 441000
 torch.manual_seed(0)
 model = MixingStyleEncoder(44100, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).cuda().train()
+model.train_backend = os.environ.get("TRAIN_BACKEND", "hip")   # "torch": encoder fwd/bwd on PyTorch-ROCm/MIOpen
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
 fe = MixingFeatureExtractor()
 crit = InfoNCELoss(0.1)
