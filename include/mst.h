@@ -182,12 +182,21 @@ int mst_encoder_update_trunk_params(mst_encoder* enc, const float* conv1_w, cons
  * dpool: gradient of the pooled activation; element (clip, band, ch, r, c) at
  *        dpool[clip*dp_clip + band*dp_band + ch*dp_ch + r*cols + c]   (layer 1: pool1 10 x W1; layer 2: pool_in 2 x W2).
  * dy:    out, gradient of the convolution output, [n_sub][B][C][rows][cols] (per band a contiguous NCHW tensor: the
- *        operand of the convolution weight / input gradient).
+ *        operand of a library convolution weight / input gradient); layer 1 only: NULL = keep it in the workspace in
+ *        accumulator order for mst_encoder_train_conv1_wgrad.
  * dfilm: [B][n_sub*192], the layer's gamma / beta slots are ACCUMULATED (+=): zero it once per step.
  * dbn:   out [n_sub][C][2] = (d BatchNorm weight, d BatchNorm bias).                                              */
 int mst_encoder_train_backward_apply(const mst_encoder* enc, int layer, int B, int frames, const float* dpool,
                                      long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream);
+
+/* conv1 weight gradient, hand-written fp32-MFMA GEMM over positions.  Call after
+ * mst_encoder_train_backward_apply(layer 1) with dy == NULL: that variant leaves d(conv1 output) in the workspace, in
+ * place of the saved activation, in accumulator order (the operand layout of this kernel).
+ * dw: out dev [n_sub][32][8][7][7] (zeroed here).  The bias gradient of a convolution that feeds a batch-statistics
+ * BatchNorm is identically zero and is not computed.                                                            */
+int mst_encoder_train_conv1_wgrad(const mst_encoder* enc, const float* logmel, int B, int frames, float* dw,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Augmentation chain.  Replaces AudioAugmenter.augment_stems src/mixing_utils.py:376-419 and

@@ -1325,7 +1325,8 @@ struct ApplyBwdParams {
   int dp_rows, dp_cols;
   float* dfilm;            // [B][nsub*192]  (+=)
   double* sums;            // [nsub][COUT][2] (+=)  S1, S2
-  float* dy;               // pass B
+  float* dy;               // pass B: NCHW per band, or NULL: in place over yraw in accumulator order (dy_acc)
+  float* dy_acc;
   int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
   double count;
   int chunks;              // pass A: blocks per (clip, band)
@@ -1453,8 +1454,25 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
     for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
   }
   unit_df<LAYER>(p, v, ac, clip, band, ch, tr, tc, g, df);
-  float* dyb = p.dy + (((size_t)band * p.B + clip) * C::COUT + ch) * (size_t)p.rows * p.cols;
   const float k = gb * ms.y;
+  if (p.dy == nullptr) {   // in place, accumulator order (operand layout of the hand-written weight gradient); 0 outside
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dy_acc + (size_t)u * NV);
+#pragma unroll
+    for (int t = 0; t < C::MT; ++t) {
+      f32x4 q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * t + r;
+        int row, col;
+        unit_geometry<LAYER>(tr, tc, g, e, row, col);
+        const float zh = (v[e] - ms.x) * ms.y;
+        q[r] = (row < p.rows && col < p.cols) ? k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2) : 0.f;
+      }
+      dst[t] = q;
+    }
+    return;
+  }
+  float* dyb = p.dy + (((size_t)band * p.B + clip) * C::COUT + ch) * (size_t)p.rows * p.cols;
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
     int row, col;
@@ -1464,6 +1482,210 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
       dyb[(size_t)row * p.cols + col] = k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 weight gradient:  dW[band][co][ci][tap] = sum over clips and positions of dy[co][pos] * x[ci][pos + tap]
+// as an fp32-MFMA GEMM with K = positions.  dy arrives in ACCUMULATOR ORDER (apply_bwd_dx_kernel, in place over yraw):
+// register e of lane (j, g) is dy[co = 16 n + j][position P(g, e)] -- exactly the A operand A[i = co][k = g] of k-step e.
+// The B operand B[k = g][n] = x[ci_n][P(g, e) + tap_n] is one ds_read_b32 from the same haloed 8-channel patch the
+// forward kernel stages (address = per-N-tile lane base + 10 g + a compile-time offset of e).
+// All 8 waves of a workgroup work on the SAME position tile and own different N-tiles of the 392 (ci, tap) columns
+// (25 tiles of 16, dealt round-robin), so a wave keeps 2 x <=4 accumulator tiles for the workgroup's whole contiguous
+// run of tiles and adds them to dW with atomics when the band changes / at the end.
+// ------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* x;          // logmel [B][8][n_mels][frames]
+  const float* dy;         // accumulator order [B][nsub][tr][tc][2][64][20]
+  float* dw;               // [nsub][32][8][49]  (+=, zeroed by the caller)
+  int B, nsub, tiles_r, tiles_c;
+  int in_rows, in_cols, in_cstride, in_bandoff;
+  long long in_clipstride;
+};
+
+// NW waves per workgroup (4: two independent workgroups per CU, so that one's loads / barrier overlap the other's MFMAs)
+template <int NW, int DBG>   // DBG: timing experiments (MST_WGRAD_DBG): 1 no dy/patch refetch, 2 no staging/barrier, 3 both
+__global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams p) {
+  using C = CC<1, 2>;
+  constexpr int PR = C::PR, PC = C::PC, CHS = PR * PC, PATCH = 8 * CHS;   // 8 x 8 x 46
+  constexpr int NTN = 25;             // N-tiles of 16 over the 392 (ci, tap) columns
+  constexpr int KN = (NTN + NW - 1) / NW;   // N-tiles per wave (at most)
+  constexpr int RPW = 64 / NW;        // patch rows a wave loads per tile
+  __shared__ float patch[2][PATCH];
+  __shared__ __attribute__((aligned(16))) float dybuf[2][2 * 64 * 20];   // the tile's dy, fetched ONCE per workgroup
+  constexpr int NDY = (2 * 64 * 5 + NW * 64 - 1) / (NW * 64);               // float4 loads per thread
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, wg = mst::xcd_remap(blockIdx.x, G);
+  const int tpb = p.B * p.tiles_r * p.tiles_c;            // tiles per band
+  const int total = p.nsub * tpb;                          // < 2^31 (checked by the host)
+  const int s_begin = (int)((long long)wg * total / G), s_end = (int)((long long)(wg + 1) * total / G);
+
+  // per N-tile lane constants
+  int nbase[KN];
+  float nmask[KN];
+#pragma unroll
+  for (int k = 0; k < KN; ++k) {
+    const int nidx = (wave + NW * k) * 16 + j;
+    const bool ok = (wave + NW * k) < NTN && nidx < 392;
+    const int ci = ok ? nidx / 49 : 0, tap = ok ? nidx % 49 : 0;
+    nbase[k] = ci * CHS + (tap / 7) * PC + tap % 7 + 10 * g;
+    nmask[k] = ok ? 1.f : 0.f;
+  }
+  const int my_nt = (NTN - wave + NW - 1) / NW;
+
+  struct TileId {
+    int band, clip, tr, tc;
+  };
+  auto decode = [&](int s) {   // only once per workgroup: the loop below advances tile ids incrementally (scalar unit)
+    TileId t;
+    t.band = s / tpb;
+    int r = s - t.band * tpb;
+    t.clip = r / (p.tiles_r * p.tiles_c);
+    r -= t.clip * p.tiles_r * p.tiles_c;
+    t.tr = r / p.tiles_c, t.tc = r - t.tr * p.tiles_c;
+    return t;
+  };
+  auto advance = [&](TileId t) {
+    if (++t.tc == p.tiles_c) {
+      t.tc = 0;
+      if (++t.tr == p.tiles_r) {
+        t.tr = 0;
+        if (++t.clip == p.B) t.clip = 0, ++t.band;
+      }
+    }
+    return t;
+  };
+  // patch rows of a tile: row = cc * PR + r -> 8 per wave, one 64-lane load each
+  auto prefetch = [&](const TileId& t, float (&pf)[RPW]) __attribute__((always_inline)) {
+    const int band = t.band, clip = t.clip, tr = t.tr, tc = t.tc;
+    const float* src = p.x + (size_t)clip * p.in_clipstride + (size_t)band * p.in_bandoff;
+    const int row0 = C::TROWS * tr - 3, cin = C::TCOLS * tc - 3 + lane;
+    const bool col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
+    const int cl = min(max(cin, 0), p.in_cols - 1);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wave * RPW + i, cc = row / PR, r = row % PR;
+      const int rin = row0 + r, rc = min(max(rin, 0), p.in_rows - 1);
+      const float v = (src + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[cl];
+      pf[i] = (col_ok && rin == rc) ? v : 0.f;
+    }
+  };
+  auto stage = [&](int buf, const float (&pf)[RPW]) __attribute__((always_inline)) {
+    if (lane < PC) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) patch[buf][(wave * RPW + i) * PC + lane] = pf[i];
+    }
+  };
+
+  f32x4 acc[2][KN];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int k = 0; k < KN; ++k) acc[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto flush = [&](int band) {
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int nidx = (wave + NW * k) * 16 + j;
+      if ((wave + NW * k) < NTN && nidx < 392) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * c + 4 * g + r;
+            atomicAdd(p.dw + ((size_t)band * 32 + co) * 392 + nidx, acc[c][k][r]);
+            acc[c][k][r] = 0.f;
+          }
+      }
+    }
+  };
+
+  if (s_begin >= s_end) return;
+  int cur_band = -1;
+  // A operand of a tile: its dy in accumulator order, both channel tiles; fetched one tile ahead into the OTHER of two
+  // explicit register sets (the loop is unrolled by two so that the compiler cannot merge them and sink the loads)
+  auto load_dy = [&](const TileId& t, f32x4 (&dq)[NDY]) __attribute__((always_inline)) {
+    const size_t u = ((((size_t)t.clip * p.nsub + t.band) * p.tiles_r + t.tr) * p.tiles_c + t.tc) * 2;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.dy + u * 64 * 20);
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) dq[i] = src[min(tid + i * NW * 64, 2 * 64 * 5 - 1)];
+  };
+  auto stage_dy = [&](int buf, const f32x4 (&dq)[NDY]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NDY; ++i)
+      if (tid + i * NW * 64 < 2 * 64 * 5) reinterpret_cast<f32x4*>(dybuf[buf])[tid + i * NW * 64] = dq[i];
+  };
+  // global -> register prefetch runs TWO tiles ahead (two explicit register sets, loop unrolled by two): the data of
+  // tile s+1 is staged into LDS at the end of tile s, a full tile after its loads were issued
+  float pfA[RPW], pfB[RPW];
+  f32x4 dqA[NDY], dqB[NDY];
+  TileId cur = decode(s_begin), nxt = cur, nxt2 = cur;
+  prefetch(cur, pfA);
+  load_dy(cur, dqA);
+  stage(0, pfA);
+  stage_dy(0, dqA);
+  if (s_begin + 1 < s_end) nxt2 = advance(cur);
+  prefetch(nxt2, pfA);      // tile s_begin + 1
+  load_dy(nxt2, dqA);
+  __syncthreads();
+  auto body = [&](int s, int buf, float (&pfs)[RPW], f32x4 (&dqs)[NDY], float (&pfn)[RPW], f32x4 (&dqn)[NDY])
+      __attribute__((always_inline)) {
+    // on entry: nxt2 = tile s+1 (its data sits in pfs / dqs); this call fetches tile s+2 into pfn / dqn
+    cur = nxt;
+    nxt = nxt2;
+    if (s + 2 < s_end) nxt2 = advance(nxt);   // past the run: re-fetch the last tile (never used)
+    const int band = cur.band;
+    if (band != cur_band) {
+      if (cur_band >= 0) flush(cur_band);
+      cur_band = band;
+    }
+    if (!(DBG & 1)) {
+      prefetch(nxt2, pfn);
+      load_dy(nxt2, dqn);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* pb = patch[buf];
+    f32x4 ac[2][5];   // A operands from the shared copy
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int t5 = 0; t5 < 5; ++t5) ac[c][t5] = reinterpret_cast<const f32x4*>(dybuf[buf])[(c * 64 + lane) * 5 + t5];
+    // B operands of an N-tile are read from LDS as a block of 20 while the 40 MFMAs of the previous N-tile run
+    float bq[2][20];
+    auto load_b = [&](int k, float (&b)[20]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 20; ++e) {
+        const int wv = e / C::WIN, pos = e % C::WIN;
+        b[e] = pb[nbase[k] + (pos / 5) * PC + 5 * wv + pos % 5];
+      }
+    };
+    load_b(0, bq[0]);
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      if (k < my_nt) {   // wave-uniform
+        if (k + 1 < KN && k + 1 < my_nt) load_b(k + 1, bq[(k + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 20; ++e) {
+          const float b = bq[k & 1][e] * nmask[k];
+          acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
+          acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!(DBG & 2)) {
+      stage(buf ^ 1, pfs);
+      stage_dy(buf ^ 1, dqs);
+      if (!(DBG & 4)) __syncthreads();
+    }
+  };
+  for (int s = s_begin; s < s_end; s += 2) {
+    body(s, 0, pfA, dqA, pfB, dqB);
+    if (s + 1 < s_end) body(s + 1, 1, pfB, dqB, pfA, dqA);
+  }
+  flush(cur_band);
 }
 
 __global__ void sums_to_dbn_kernel(const double* sums, float* dbn, int n) {
@@ -1949,7 +2171,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
 int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int frames, const float* dpool,
                                      long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(e && dpool && dy && dfilm && dbn, "mst_encoder_train_backward_apply: NULL argument");
+  MST_REQUIRE(e && dpool && dfilm && dbn, "mst_encoder_train_backward_apply: NULL argument");
+  MST_REQUIRE(dy || layer == 1, "mst_encoder_train_backward_apply: dy may be NULL (in-place accumulator order) for layer 1 only");
   MST_REQUIRE(e->sub == 2 && (layer == 1 || layer == 2) && B > 0 && frames >= 20, "mst_encoder_train_backward_apply: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
@@ -1968,6 +2191,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * 8, st));
   if (layer == 1) {
     p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
+    p.dy_acc = reinterpret_cast<float*>(ws + T.y1);
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn1), p.bn_w = e->bn1w, p.bn_b = e->bn1b;
     p.dp_rows = e->H1, p.dp_cols = L.W1, p.tiles_r = T.tr1, p.tiles_c = T.tc1;
     p.rows = e->cfg.split_size, p.cols = frames, p.goff = 0, p.boff = 32;
@@ -2016,6 +2240,40 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
       {e->c1b, conv1_b, ns * 32}, {e->bn1w, bn1_w, ns * 32}, {e->bn1b, bn1_b, ns * 32},
       {e->c2b, conv2_b, ns * 64}, {e->bn2w, bn2_w, ns * 64}, {e->bn2b, bn2_b, ns * 64}};
   for (const auto& c : cp) MST_HIP_CHECK(hipMemcpyAsync(c.dst, c.src, (size_t)c.n * 4, hipMemcpyDeviceToDevice, st));
+  return MST_OK;
+}
+
+int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int B, int frames, float* dw,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && logmel && dw, "mst_encoder_train_conv1_wgrad: NULL argument");
+  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20, "mst_encoder_train_conv1_wgrad: bad arguments");
+  const TrainLayout T = train_layout(e, B, frames);
+  if (!workspace || workspace_bytes < T.total)
+    return mst::fail(MST_ENOMEM, "mst_encoder_train_conv1_wgrad: workspace %zu B < required %zu B", workspace_bytes, T.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int ns = e->cfg.n_subbands;
+  MST_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ns * 32 * 392 * 4, st));
+  WgradParams wp{logmel, reinterpret_cast<const float*>(ws + T.y1), dw, B, ns, T.tr1, T.tc1,
+                 e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
+                 (long long)8 * e->cfg.n_mels * frames};
+  const long long total = (long long)ns * B * T.tr1 * T.tc1;
+  MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv1_wgrad: too many tiles");
+  const int dbg = getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0;
+  const int nw = getenv("MST_WGRAD_WAVES") ? atoi(getenv("MST_WGRAD_WAVES")) : 8;
+  if (nw == 8) {
+    const int g8 = (int)std::min<long long>(e->num_cus, total);
+    if (dbg == 3) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 3>), dim3(g8), dim3(512), 0, st, wp);
+    else if (dbg == 1) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 1>), dim3(g8), dim3(512), 0, st, wp);
+    else if (dbg == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 2>), dim3(g8), dim3(512), 0, st, wp);
+    else if (dbg == 4) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 4>), dim3(g8), dim3(512), 0, st, wp);
+    else hipLaunchKernelGGL((conv1_wgrad_kernel<8, 0>), dim3(g8), dim3(512), 0, st, wp);
+  } else {
+    const int g4 = (int)std::min<long long>(2 * e->num_cus, total);
+    if (dbg == 3) hipLaunchKernelGGL((conv1_wgrad_kernel<4, 3>), dim3(g4), dim3(256), 0, st, wp);
+    else hipLaunchKernelGGL((conv1_wgrad_kernel<4, 0>), dim3(g4), dim3(256), 0, st, wp);
+  }
+  MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
 

@@ -12,6 +12,8 @@ Forward paths
 """
 import ctypes as C
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -259,7 +261,20 @@ class HipEncoder:
                                                                   _lib.stream_ptr(ts[0].device)),
                        "mst_encoder_update_trunk_params")
 
-    def backward_apply(self, layer, dpool, dfilm, B, frames):
+    def conv1_wgrad(self, logmel, B, frames):
+        """conv1 weight gradient (n_sub, 32, 8, 7, 7) from the d(conv1 output) that `backward_apply(1, ..., inplace=True)`
+        left in the workspace (`mst_encoder_train_conv1_wgrad`)."""
+        L = _lib.lib()
+        dw = torch.empty(self.n_sub, 32, 8, 7, 7, device=logmel.device)
+        need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
+        lm = logmel.contiguous().float()
+        with torch.cuda.device(lm.device):
+            _lib.check(L.mst_encoder_train_conv1_wgrad(self._h, _lib.dptr(lm), B, frames, _lib.dptr(dw),
+                                                       _lib.dptr(self._ws_train), need, _lib.stream_ptr(lm.device)),
+                       "mst_encoder_train_conv1_wgrad")
+        return dw
+
+    def backward_apply(self, layer, dpool, dfilm, B, frames, inplace=False):
         """Backward of pool/ReLU/FiLM/BatchNorm(train) of conv layer 1 or 2 from the activations the last
         `forward_train` call left in its workspace (`mst_encoder_train_backward_apply`).
         dpool: layer 1 (B, n_sub, 32, 10, W1) or any tensor with those dims and arbitrary clip / band / channel
@@ -271,7 +286,7 @@ class HipEncoder:
         if layer == 1:
             assert dpool.dim() == 5 and dpool.stride(4) == 1 and dpool.stride(3) == W1
             st = (dpool.stride(0), dpool.stride(1), dpool.stride(2))
-            dy = torch.empty(self.n_sub, B, 32, self.split, frames, device=dev)
+            dy = None if inplace else torch.empty(self.n_sub, B, 32, self.split, frames, device=dev)
             dbn = torch.empty(self.n_sub, 32, 2, device=dev)
         else:
             dpool = dpool.contiguous()
@@ -322,12 +337,17 @@ class HipEncoder:
         return (emb, out) if taps else emb
 
 
+_TRAIN_TIMING = bool(os.environ.get("MST_TRAIN_TIMING"))
+_CONV1_WGRAD_MIOPEN = os.environ.get("MST_CONV1_WGRAD", "") == "miopen"
+
+
 class _HipTrunk(torch.autograd.Function):
     """The 11 x [conv -> BatchNorm(batch statistics) -> FiLM -> ReLU -> max-pool] x 2 trunk for training.
     Forward: libmst.so (`mst_encoder_forward_train`, raw conv outputs kept).  Backward: pool / ReLU / FiLM / BatchNorm in
     libmst.so (`mst_encoder_train_backward_apply`); the convolution weight / input gradients are still taken from
     PyTorch-ROCm (`aten.convolution_backward`, MIOpen) per sub-band -- the hand-written wgrad / dgrad kernels are the
     remaining piece of SURVEY 8 f1."""
+    last_timing = None
 
     @staticmethod
     def forward(ctx, enc, logmel, film, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b, drop_p):
@@ -349,23 +369,46 @@ class _HipTrunk(torch.autograd.Function):
         logmel, p1, c1w, c2w, mask = ctx.saved_tensors
         ns, ov, sp = enc.n_sub, enc.overlap, enc.split
         bw = torch.ops.aten.convolution_backward
+        marks = []
+
+        def mark(name):   # MST_TRAIN_TIMING=1: per-section GPU times of the last backward in _HipTrunk.last_timing
+            if _TRAIN_TIMING:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((name, e))
+        mark("start")
         dfilm = torch.zeros(B, ns * 192, device=logmel.device)
         dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr)
+        mark("apply_bwd2")
         gi, gw2, gb2 = [], [], []
         for i in range(ns):
             a, b, c = bw(dy2[i], p1[:, i].contiguous(), c2w[i], [64], [1, 1], [3, 3], [1, 1], False, [0, 0], 1,
                          [True, True, True])
             gi.append(a), gw2.append(b), gb2.append(c)
+        mark("conv2_bwd(miopen)")
         dp1 = torch.stack(gi, 1)
         if mask is not None:
             dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
-        dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
-        gw1, gb1 = [], []
-        for i in range(ns):
-            _, b, c = bw(dy1[i], logmel[:, :, i * ov:i * ov + sp, :].contiguous(), c1w[i], [32], [1, 1], [3, 3], [1, 1],
-                         False, [0, 0], 1, [False, True, True])
-            gw1.append(b), gb1.append(c)
-        return (None, None, dfilm, torch.stack(gw1), torch.stack(gb1), dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(),
+        mark("stack+mask")
+        if _CONV1_WGRAD_MIOPEN:   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (for A/B checks)
+            dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
+            mark("apply_bwd1")
+            gw1, gb1 = [], []
+            for i in range(ns):
+                _, b, c = bw(dy1[i], logmel[:, :, i * ov:i * ov + sp, :].contiguous(), c1w[i], [32], [1, 1], [3, 3],
+                             [1, 1], False, [0, 0], 1, [False, True, True])
+                gw1.append(b), gb1.append(c)
+            gw1, gb1 = torch.stack(gw1), torch.stack(gb1)
+        else:                     # hand-written fp32-MFMA weight gradient on dy in accumulator order
+            _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True)
+            mark("apply_bwd1")
+            gw1 = enc.conv1_wgrad(logmel, B, Fr)
+            gb1 = torch.zeros(ns, 32, device=logmel.device)   # exactly 0 in front of a batch-statistics BatchNorm
+        mark("conv1_wgrad")
+        if _TRAIN_TIMING:
+            torch.cuda.synchronize()
+            _HipTrunk.last_timing = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
+        return (None, None, dfilm, gw1, gb1, dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(),
                 torch.stack(gw2), torch.stack(gb2), dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous(), None)
 
 

@@ -40,3 +40,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"B={B}: train step {dt * 1e3:.1f} ms = {B / 3 / dt:.1f} triplets/s, loss {l.item():.4f}, "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+from mst_amd import model as _m
+if _m._HipTrunk.last_timing:
+    print("backward sections (ms):", _m._HipTrunk.last_timing)
+
