@@ -1509,7 +1509,9 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   using C = CC<1, 2>;
   constexpr int PR = C::PR, PC = C::PC, CHS = PR * PC, PATCH = 8 * CHS;   // 8 x 8 x 46
   constexpr int NTN = 25;             // N-tiles of 16 over the 392 (ci, tap) columns
-  constexpr int KN = (NTN + NW - 1) / NW;   // N-tiles per wave (at most)
+  constexpr int KF = (NTN - 1) / NW;        // full N-tiles per wave: nt = wave + NW*k, k < KF (24 of the 25)
+  constexpr bool SHARED = true;             // N-tile 24 (half empty): its 20 k-steps are dealt over the waves
+  constexpr int KN = KF + 1;
   constexpr int RPW = 64 / NW;        // patch rows a wave loads per tile
   __shared__ float patch[2][PATCH];
   __shared__ __attribute__((aligned(16))) float dybuf[2][2 * 64 * 20];   // the tile's dy, fetched ONCE per workgroup
@@ -1526,14 +1528,19 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   int nbase[KN];
   float nmask[KN];
 #pragma unroll
-  for (int k = 0; k < KN; ++k) {
+  for (int k = 0; k < KF; ++k) {
     const int nidx = (wave + NW * k) * 16 + j;
-    const bool ok = (wave + NW * k) < NTN && nidx < 392;
+    const bool ok = true;   // N-tiles 0..23 are full
     const int ci = ok ? nidx / 49 : 0, tap = ok ? nidx % 49 : 0;
     nbase[k] = ci * CHS + (tap / 7) * PC + tap % 7 + 10 * g;
     nmask[k] = ok ? 1.f : 0.f;
   }
-  const int my_nt = (NTN - wave + NW - 1) / NW;
+  // shared N-tile 24: waves 0..3 take 3 k-steps, waves 4..7 two (NW = 8); with NW = 4 every wave takes 5
+  const int sh_cnt = NW == 8 ? (wave < 4 ? 3 : 2) : 5;
+  const int sh_e0 = NW == 8 ? (wave < 4 ? 3 * wave : 12 + 2 * (wave - 4)) : 5 * wave;
+  const int sh_nidx = (NTN - 1) * 16 + j;
+  const int sh_base = (sh_nidx < 392 ? (sh_nidx / 49) * CHS + ((sh_nidx % 49) / 7) * PC + (sh_nidx % 49) % 7 : 0) + 10 * g;
+  const float sh_mask = sh_nidx < 392 ? 1.f : 0.f;
 
   struct TileId {
     int band, clip, tr, tc;
@@ -1558,24 +1565,46 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     return t;
   };
   // patch rows of a tile: row = cc * PR + r -> 8 per wave, one 64-lane load each
-  auto prefetch = [&](const TileId& t, float (&pf)[RPW]) __attribute__((always_inline)) {
-    const int band = t.band, clip = t.clip, tr = t.tr, tc = t.tc;
-    const float* src = p.x + (size_t)clip * p.in_clipstride + (size_t)band * p.in_bandoff;
-    const int row0 = C::TROWS * tr - 3, cin = C::TCOLS * tc - 3 + lane;
-    const bool col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
-    const int cl = min(max(cin, 0), p.in_cols - 1);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
+  // prefetch of a tile in RPW + NDY pieces (one vector-memory instruction each), issued BETWEEN the MFMAs of the
+  // current tile: all waves of the workgroup run in lockstep (one barrier per tile), so a block of loads at the top
+  // of the tile would leave every matrix pipe idle while it issues
+  const float* pf_src = p.x;
+  int pf_row0 = 0, pf_cl = 0;
+  bool pf_colok = false;
+  const f32x4* dy_src = reinterpret_cast<const f32x4*>(p.dy);
+  auto prefetch_setup = [&](const TileId& t) __attribute__((always_inline)) {
+    pf_src = p.x + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
+    pf_row0 = C::TROWS * t.tr - 3;
+    const int cin = C::TCOLS * t.tc - 3 + lane;
+    pf_colok = lane < PC && cin >= 0 && cin < p.in_cols;
+    pf_cl = min(max(cin, 0), p.in_cols - 1);
+    const size_t u = ((((size_t)t.clip * p.nsub + t.band) * p.tiles_r + t.tr) * p.tiles_c + t.tc) * 2;
+    dy_src = reinterpret_cast<const f32x4*>(p.dy + u * 64 * 20);
+  };
+  auto prefetch_piece = [&](int i, float (&pf)[RPW], f32x4 (&dq)[NDY], unsigned& pmask) __attribute__((always_inline)) {
+    if ((DBG & 8) && i < RPW) return;
+    if ((DBG & 16) && i >= RPW) return;
+    if (i < RPW) {
       const int row = wave * RPW + i, cc = row / PR, r = row % PR;
-      const int rin = row0 + r, rc = min(max(rin, 0), p.in_rows - 1);
-      const float v = (src + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[cl];
-      pf[i] = (col_ok && rin == rc) ? v : 0.f;
+      const int rin = pf_row0 + r, rc = min(max(rin, 0), p.in_rows - 1);
+      // the out-of-image mask is applied when the row is staged: touching the value here would make the wave wait
+      // for the load on the spot
+      pf[i] = (pf_src + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[pf_cl];
+      if (pf_colok && rin == rc) pmask |= 1u << i;
+    } else if (i < RPW + NDY) {
+      dq[i - RPW] = dy_src[min(tid + (i - RPW) * NW * 64, 2 * 64 * 5 - 1)];
     }
   };
-  auto stage = [&](int buf, const float (&pf)[RPW]) __attribute__((always_inline)) {
+  auto prefetch = [&](const TileId& t, float (&pf)[RPW], f32x4 (&dq)[NDY], unsigned& pmask) __attribute__((always_inline)) {
+    prefetch_setup(t);
+    pmask = 0;
+#pragma unroll
+    for (int i = 0; i < RPW + NDY; ++i) prefetch_piece(i, pf, dq, pmask);
+  };
+  auto stage = [&](int buf, const float (&pf)[RPW], unsigned pmask) __attribute__((always_inline)) {
     if (lane < PC) {
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) patch[buf][(wave * RPW + i) * PC + lane] = pf[i];
+      for (int i = 0; i < RPW; ++i) patch[buf][(wave * RPW + i) * PC + lane] = ((pmask >> i) & 1u) ? pf[i] : 0.f;
     }
   };
 
@@ -1587,8 +1616,9 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   auto flush = [&](int band) {
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
-      const int nidx = (wave + NW * k) * 16 + j;
-      if ((wave + NW * k) < NTN && nidx < 392) {
+      const int nt = k < KF ? wave + NW * k : NTN - 1;
+      const int nidx = nt * 16 + j;
+      if (nidx < 392) {
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -1605,12 +1635,6 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   int cur_band = -1;
   // A operand of a tile: its dy in accumulator order, both channel tiles; fetched one tile ahead into the OTHER of two
   // explicit register sets (the loop is unrolled by two so that the compiler cannot merge them and sink the loads)
-  auto load_dy = [&](const TileId& t, f32x4 (&dq)[NDY]) __attribute__((always_inline)) {
-    const size_t u = ((((size_t)t.clip * p.nsub + t.band) * p.tiles_r + t.tr) * p.tiles_c + t.tc) * 2;
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.dy + u * 64 * 20);
-#pragma unroll
-    for (int i = 0; i < NDY; ++i) dq[i] = src[min(tid + i * NW * 64, 2 * 64 * 5 - 1)];
-  };
   auto stage_dy = [&](int buf, const f32x4 (&dq)[NDY]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NDY; ++i)
@@ -1620,17 +1644,16 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   // tile s+1 is staged into LDS at the end of tile s, a full tile after its loads were issued
   float pfA[RPW], pfB[RPW];
   f32x4 dqA[NDY], dqB[NDY];
+  unsigned pmA = 0, pmB = 0;
   TileId cur = decode(s_begin), nxt = cur, nxt2 = cur;
-  prefetch(cur, pfA);
-  load_dy(cur, dqA);
-  stage(0, pfA);
+  prefetch(cur, pfA, dqA, pmA);
+  stage(0, pfA, pmA);
   stage_dy(0, dqA);
   if (s_begin + 1 < s_end) nxt2 = advance(cur);
-  prefetch(nxt2, pfA);      // tile s_begin + 1
-  load_dy(nxt2, dqA);
+  prefetch(nxt2, pfA, dqA, pmA);      // tile s_begin + 1
   __syncthreads();
-  auto body = [&](int s, int buf, float (&pfs)[RPW], f32x4 (&dqs)[NDY], float (&pfn)[RPW], f32x4 (&dqn)[NDY])
-      __attribute__((always_inline)) {
+  auto body = [&](int s, int buf, float (&pfs)[RPW], f32x4 (&dqs)[NDY], unsigned& pms, float (&pfn)[RPW], f32x4 (&dqn)[NDY],
+                  unsigned& pmn) __attribute__((always_inline)) {
     // on entry: nxt2 = tile s+1 (its data sits in pfs / dqs); this call fetches tile s+2 into pfn / dqn
     cur = nxt;
     nxt = nxt2;
@@ -1640,12 +1663,11 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
       if (cur_band >= 0) flush(cur_band);
       cur_band = band;
     }
-    if (!(DBG & 1)) {
-      prefetch(nxt2, pfn);
-      load_dy(nxt2, dqn);
-    }
+    prefetch_setup(nxt2);
+    pmn = 0;
     __builtin_amdgcn_sched_barrier(0);
     const float* pb = patch[buf];
+    const float* dyl = dybuf[buf];
     f32x4 ac[2][5];   // A operands from the shared copy
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1661,29 +1683,45 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
       }
     };
     load_b(0, bq[0]);
+    int piece = 0;
 #pragma unroll
-    for (int k = 0; k < KN; ++k) {
-      if (k < my_nt) {   // wave-uniform
-        if (k + 1 < KN && k + 1 < my_nt) load_b(k + 1, bq[(k + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < KF; ++k) {   // the wave's own full N-tiles
+      if (k + 1 < KF) load_b(k + 1, bq[(k + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int e = 0; e < 20; ++e) {
-          const float b = bq[k & 1][e] * nmask[k];
-          acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
-          acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
+      for (int e = 0; e < 20; ++e) {
+        const float b = bq[k & 1][e];
+        acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
+        acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
+        if (!(DBG & 1) && (e % 5) == 2) {   // one prefetch instruction per 10 MFMAs
+          prefetch_piece(piece, pfn, dqn, pmn);
+          ++piece;
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (SHARED) {   // the last, shared N-tile: this wave's share of its 20 k-steps
+#pragma unroll
+      for (int q = 0; q < (NW == 8 ? 3 : 5); ++q) {
+        if (q < sh_cnt) {   // wave-uniform
+          const int e = sh_e0 + q;
+          const int wv = e / C::WIN, pos = e % C::WIN;
+          const float b = pb[sh_base + (pos / 5) * PC + 5 * wv + pos % 5] * sh_mask;
+          const float a0 = dyl[(0 * 64 + lane) * 20 + e], a1 = dyl[(1 * 64 + lane) * 20 + e];
+          acc[0][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][KF], 0, 0, 0);
+          acc[1][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][KF], 0, 0, 0);
+        }
+      }
+    }
     if (!(DBG & 2)) {
-      stage(buf ^ 1, pfs);
+      stage(buf ^ 1, pfs, pms);
       stage_dy(buf ^ 1, dqs);
       if (!(DBG & 4)) __syncthreads();
     }
   };
   for (int s = s_begin; s < s_end; s += 2) {
-    body(s, 0, pfA, dqA, pfB, dqB);
-    if (s + 1 < s_end) body(s + 1, 1, pfB, dqB, pfA, dqA);
+    body(s, 0, pfA, dqA, pmA, pfB, dqB, pmB);
+    if (s + 1 < s_end) body(s + 1, 1, pfB, dqB, pmB, pfA, dqA, pmA);
   }
   flush(cur_band);
 }
@@ -2267,6 +2305,8 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
     else if (dbg == 1) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 1>), dim3(g8), dim3(512), 0, st, wp);
     else if (dbg == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 2>), dim3(g8), dim3(512), 0, st, wp);
     else if (dbg == 4) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 4>), dim3(g8), dim3(512), 0, st, wp);
+    else if (dbg == 8) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 8>), dim3(g8), dim3(512), 0, st, wp);
+    else if (dbg == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 16>), dim3(g8), dim3(512), 0, st, wp);
     else hipLaunchKernelGGL((conv1_wgrad_kernel<8, 0>), dim3(g8), dim3(512), 0, st, wp);
   } else {
     const int g4 = (int)std::min<long long>(2 * e->num_cus, total);
