@@ -198,6 +198,13 @@ int mst_encoder_train_backward_apply(const mst_encoder* enc, int layer, int B, i
 int mst_encoder_train_conv1_wgrad(const mst_encoder* enc, const float* logmel, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv2 weight gradient, same scheme (dy of layer 2 is always left in the workspace in accumulator order by
+ * mst_encoder_train_backward_apply(layer 2), next to the NCHW copy it returns).
+ * pool1: dev [B][n_sub][32][H1][W1], the (dropped-out) input of conv2 as the training forward produced it.
+ * dw:    out dev [n_sub][64][32][7][7] (zeroed here).                                                           */
+int mst_encoder_train_conv2_wgrad(const mst_encoder* enc, const float* pool1, int B, int frames, float* dw,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Augmentation chain.  Replaces AudioAugmenter.augment_stems src/mixing_utils.py:376-419 and
  * apply_spectral_tilt :421-433, apply_compression :435-447, apply_bandwidth_limit :449-456,

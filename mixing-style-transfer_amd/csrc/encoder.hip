@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
   }
   unit_df<LAYER>(p, v, ac, clip, band, ch, tr, tc, g, df);
   const float k = gb * ms.y;
-  if (p.dy == nullptr) {   // in place, accumulator order (operand layout of the hand-written weight gradient); 0 outside
+  if (p.dy_acc != nullptr) {   // in place, accumulator order (operand layout of the hand-written weight gradient); 0 outside
     f32x4* dst = reinterpret_cast<f32x4*>(p.dy_acc + (size_t)u * NV);
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
@@ -1470,8 +1470,8 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
       }
       dst[t] = q;
     }
-    return;
   }
+  if (p.dy == nullptr) return;
   float* dyb = p.dy + (((size_t)band * p.B + clip) * C::COUT + ch) * (size_t)p.rows * p.cols;
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
@@ -1613,7 +1613,7 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int k = 0; k < KN; ++k) acc[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto flush = [&](int band) {
+  auto flush = [&](int band) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < KN; ++k) {
       const int nt = k < KF ? wave + NW * k : NTN - 1;
@@ -1724,6 +1724,212 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     if (s + 1 < s_end) body(s + 1, 1, pfB, dqB, pmB, pfA, dqA, pmA);
   }
   flush(cur_band);
+}
+
+// ------------------------------------------------------------------------------------------
+// conv2 weight gradient, same scheme as conv1_wgrad_kernel: dW2[band][co][ci][tap] with M = 64 output channels (4 tiles),
+// the 32 x 49 (ci, tap) columns in 4 chunks of 8 input channels (392 columns = 24 full N-tiles + a shared half tile,
+// exactly conv1's N structure), K = positions: 8 x 8 tiles of the 10 x 344 plane, dy2 in accumulator order (16 values
+// per lane: position (4 (g >> 1) + e / 4, 4 (g & 1) + e % 4)).  Tiles of the second tile row hold output rows 8 and 9
+// only: their k-steps e >= 8 are all zero and are skipped.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradParams p) {
+  constexpr int NW = 8, PR = 14, PC = 14, CHS = PR * PC, PATCH = 8 * CHS;   // 8 channels x 14 x 14
+  constexpr int NTN = 25, KF = 3, KN = KF + 1, NCH = 4;
+  constexpr int NPF = 4;        // patch elements per thread: flat index f = tid + 512 i over [8*14 rows][16 pitch]
+  constexpr int NDY = 2;        // float4 of dy per thread: 4 * 64 * 16 floats per tile
+  __shared__ float patch[2][PATCH];
+  __shared__ __attribute__((aligned(16))) float dybuf[2][4 * 64 * 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int G = gridDim.x, wg = mst::xcd_remap(blockIdx.x, G);
+  const int tpc = p.B * p.tiles_r * p.tiles_c;           // tiles per (band, chunk)
+  const int total = p.nsub * NCH * tpc;
+  const int s_begin = (int)((long long)wg * total / G), s_end = (int)((long long)(wg + 1) * total / G);
+  if (s_begin >= s_end) return;
+
+  const int goff = (4 * (g >> 1)) * PC + 4 * (g & 1);
+  int nbase[KF];
+#pragma unroll
+  for (int k = 0; k < KF; ++k) {
+    const int nidx = (wave + NW * k) * 16 + j, ci = nidx / 49, tap = nidx % 49;
+    nbase[k] = ci * CHS + (tap / 7) * PC + tap % 7 + goff;
+  }
+  const int sh_nidx = (NTN - 1) * 16 + j;
+  const int sh_base = (sh_nidx < 392 ? (sh_nidx / 49) * CHS + ((sh_nidx % 49) / 7) * PC + (sh_nidx % 49) % 7 : 0) + goff;
+  const float sh_mask = sh_nidx < 392 ? 1.f : 0.f;
+
+  struct Item {
+    int band, chunk, clip, tr, tc;
+  };
+  auto decode = [&](int s) __attribute__((always_inline)) {
+    Item t;
+    t.band = s / (NCH * tpc);
+    int r = s - t.band * NCH * tpc;
+    t.chunk = r / tpc;
+    r -= t.chunk * tpc;
+    t.clip = r / (p.tiles_r * p.tiles_c);
+    r -= t.clip * p.tiles_r * p.tiles_c;
+    t.tr = r / p.tiles_c, t.tc = r - t.tr * p.tiles_c;
+    return t;
+  };
+  auto advance = [&](Item t) __attribute__((always_inline)) {
+    if (++t.tc == p.tiles_c) {
+      t.tc = 0;
+      if (++t.tr == p.tiles_r) {
+        t.tr = 0;
+        if (++t.clip == p.B) {
+          t.clip = 0;
+          if (++t.chunk == NCH) t.chunk = 0, ++t.band;
+        }
+      }
+    }
+    return t;
+  };
+
+  const float* pf_src = p.x;
+  int pf_row0 = 0, pf_col0 = 0;
+  const f32x4* dy_src = reinterpret_cast<const f32x4*>(p.dy);
+  auto prefetch_setup = [&](const Item& t) __attribute__((always_inline)) {
+    pf_src = p.x + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff + (size_t)(8 * t.chunk) * p.in_cstride;
+    pf_row0 = 8 * t.tr - 3, pf_col0 = 8 * t.tc - 3;
+    const size_t u = ((((size_t)t.clip * p.nsub + t.band) * p.tiles_r + t.tr) * p.tiles_c + t.tc) * 4;
+    dy_src = reinterpret_cast<const f32x4*>(p.dy + u * 64 * 16);
+  };
+  auto prefetch_piece = [&](int i, float (&pf)[NPF], f32x4 (&dq)[NDY], unsigned& pmask) __attribute__((always_inline)) {
+    if (i < NPF) {
+      const int f = tid + kConvThreads * i, row = f >> 4, col = f & 15;
+      const int cc = min(row / PR, 7), r = row % PR;
+      const int rin = pf_row0 + r, cin = pf_col0 + col;
+      const int rc = min(max(rin, 0), p.in_rows - 1), cl = min(max(cin, 0), p.in_cols - 1);
+      pf[i] = (pf_src + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[cl];
+      if (row < 8 * PR && col < PC && rin == rc && cin == cl) pmask |= 1u << i;
+    } else if (i < NPF + NDY) {
+      dq[i - NPF] = dy_src[tid + (i - NPF) * kConvThreads];
+    }
+  };
+  auto stage = [&](int buf, const float (&pf)[NPF], const f32x4 (&dq)[NDY], unsigned pmask) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      const int f = tid + kConvThreads * i, row = f >> 4, col = f & 15;
+      if (row < 8 * PR && col < PC) patch[buf][row * PC + col] = ((pmask >> i) & 1u) ? pf[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) reinterpret_cast<f32x4*>(dybuf[buf])[tid + i * kConvThreads] = dq[i];
+  };
+
+  f32x4 acc[4][KN];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < KN; ++k) acc[c][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto flush = [&](int band, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KN; ++k) {
+      const int nt = k < KF ? wave + NW * k : NTN - 1;
+      const int nidx = nt * 16 + j;
+      if (nidx < 392) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 16 * c + 4 * g + r;
+            atomicAdd(p.dw + ((size_t)band * 64 + co) * 1568 + chunk * 392 + nidx, acc[c][k][r]);
+            acc[c][k][r] = 0.f;
+          }
+      }
+    }
+  };
+
+  float pfA[NPF], pfB[NPF];
+  f32x4 dqA[NDY], dqB[NDY];
+  unsigned pmA = 0, pmB = 0;
+  Item cur = decode(s_begin), nxt = cur, nxt2 = cur;
+  int cur_band = -1, cur_chunk = -1;
+  prefetch_setup(cur);
+#pragma unroll
+  for (int i = 0; i < NPF + NDY; ++i) prefetch_piece(i, pfA, dqA, pmA);
+  stage(0, pfA, dqA, pmA);
+  if (s_begin + 1 < s_end) nxt2 = advance(cur);
+  prefetch_setup(nxt2);
+  pmA = 0;
+#pragma unroll
+  for (int i = 0; i < NPF + NDY; ++i) prefetch_piece(i, pfA, dqA, pmA);
+  __syncthreads();
+
+  auto body = [&](int s, int buf, float (&pfs)[NPF], f32x4 (&dqs)[NDY], unsigned& pms, float (&pfn)[NPF], f32x4 (&dqn)[NDY],
+                  unsigned& pmn) __attribute__((always_inline)) {
+    cur = nxt;
+    nxt = nxt2;
+    if (s + 2 < s_end) nxt2 = advance(nxt);
+    if (cur.band != cur_band || cur.chunk != cur_chunk) {
+      if (cur_band >= 0) flush(cur_band, cur_chunk);
+      cur_band = cur.band, cur_chunk = cur.chunk;
+    }
+    prefetch_setup(nxt2);
+    pmn = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    const float* pb = patch[buf];
+    const float* dyl = dybuf[buf];
+    f32x4 ac[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) ac[c][t4] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + t4];
+    const bool low = __builtin_amdgcn_readfirstlane(cur.tr) == 1;   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
+    float bq[2][16];
+    auto load_b = [&](int k, float (&b)[16]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) b[e] = pb[nbase[k] + (e >> 2) * PC + (e & 3)];
+    };
+    load_b(0, bq[0]);
+    auto mma = [&](auto ne_c) __attribute__((always_inline)) {   // NE k-steps per N-tile: 16, or 8 in the low tiles
+      constexpr int NE = decltype(ne_c)::value;
+      int piece = 0;
+#pragma unroll
+      for (int k = 0; k < KF; ++k) {
+        if (k + 1 < KF) load_b(k + 1, bq[(k + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const float b = bq[k & 1][e];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c][e >> 2][e & 3], b, acc[c][k], 0, 0, 0);
+          if ((e & 3) == 2 && e < 8) {   // two prefetch instructions per N-tile, in the k-steps every tile executes
+            prefetch_piece(piece, pfn, dqn, pmn);
+            ++piece;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if (low) mma(std::integral_constant<int, 8>{});
+    else mma(std::integral_constant<int, 16>{});
+    {   // shared N-tile 24: two k-steps per wave (one in the low tiles)
+      const int e0 = low ? wave : 2 * wave, cnt = low ? 1 : 2;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (q < cnt) {
+          const int e = e0 + q;
+          const float b = pb[sh_base + (e >> 2) * PC + (e & 3)] * sh_mask;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float a = dyl[(c * 64 + lane) * 16 + e];
+            acc[c][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c][KF], 0, 0, 0);
+          }
+        }
+      }
+    }
+    stage(buf ^ 1, pfs, dqs, pms);
+    __syncthreads();
+  };
+  for (int s = s_begin; s < s_end; s += 2) {
+    body(s, 0, pfA, dqA, pmA, pfB, dqB, pmB);
+    if (s + 1 < s_end) body(s + 1, 1, pfB, dqB, pmB, pfA, dqA, pmA);
+  }
+  flush(cur_band, cur_chunk);
 }
 
 __global__ void sums_to_dbn_kernel(const double* sums, float* dbn, int n) {
@@ -2210,7 +2416,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
                                      long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && dpool && dfilm && dbn, "mst_encoder_train_backward_apply: NULL argument");
-  MST_REQUIRE(dy || layer == 1, "mst_encoder_train_backward_apply: dy may be NULL (in-place accumulator order) for layer 1 only");
+
   MST_REQUIRE(e->sub == 2 && (layer == 1 || layer == 2) && B > 0 && frames >= 20, "mst_encoder_train_backward_apply: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
@@ -2229,13 +2435,14 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * 8, st));
   if (layer == 1) {
     p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
-    p.dy_acc = reinterpret_cast<float*>(ws + T.y1);
+    p.dy_acc = dy ? nullptr : reinterpret_cast<float*>(ws + T.y1);
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn1), p.bn_w = e->bn1w, p.bn_b = e->bn1b;
     p.dp_rows = e->H1, p.dp_cols = L.W1, p.tiles_r = T.tr1, p.tiles_c = T.tc1;
     p.rows = e->cfg.split_size, p.cols = frames, p.goff = 0, p.boff = 32;
     p.count = (double)B * e->cfg.split_size * frames;
   } else {
     p.yraw = reinterpret_cast<const float*>(ws + T.y2), p.aff = reinterpret_cast<const float2*>(ws + L.aff2);
+    p.dy_acc = reinterpret_cast<float*>(ws + T.y2);   // layer 2: always kept in accumulator order as well (conv2 wgrad)
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn2), p.bn_w = e->bn2w, p.bn_b = e->bn2b;
     p.dp_rows = e->FD, p.dp_cols = L.W2, p.tiles_r = T.tr2, p.tiles_c = T.tc2;
     p.rows = e->H1, p.cols = L.W1, p.goff = 64, p.boff = 128;
@@ -2313,6 +2520,28 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
     if (dbg == 3) hipLaunchKernelGGL((conv1_wgrad_kernel<4, 3>), dim3(g4), dim3(256), 0, st, wp);
     else hipLaunchKernelGGL((conv1_wgrad_kernel<4, 0>), dim3(g4), dim3(256), 0, st, wp);
   }
+  MST_HIP_CHECK(hipGetLastError());
+  return MST_OK;
+}
+
+int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int B, int frames, float* dw,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && pool1 && dw, "mst_encoder_train_conv2_wgrad: NULL argument");
+  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20, "mst_encoder_train_conv2_wgrad: bad arguments");
+  const TrainLayout T = train_layout(e, B, frames);
+  const WsLayout& L = T.base;
+  if (!workspace || workspace_bytes < T.total)
+    return mst::fail(MST_ENOMEM, "mst_encoder_train_conv2_wgrad: workspace %zu B < required %zu B", workspace_bytes, T.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int ns = e->cfg.n_subbands;
+  MST_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ns * 64 * 1568 * 4, st));
+  WgradParams wp{pool1, reinterpret_cast<const float*>(ws + T.y2), dw, B, ns, T.tr2, T.tc2,
+                 e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1};
+  const long long total = (long long)ns * 4 * B * T.tr2 * T.tc2;
+  MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
+  const int g = (int)std::min<long long>(e->num_cus, total);
+  hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
