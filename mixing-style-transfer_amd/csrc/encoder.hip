@@ -1501,6 +1501,7 @@ struct WgradParams {
   int B, nsub, tiles_r, tiles_c;
   int in_rows, in_cols, in_cstride, in_bandoff;
   long long in_clipstride;
+  int dbg;                 // timing experiments (conv2 kernel): 1 skip MFMAs, 2 skip prefetch, 4 skip the A-operand LDS reads
 };
 
 // NW waves per workgroup (4: two independent workgroups per CU, so that one's loads / barrier overlap the other's MFMAs)
@@ -1876,7 +1877,8 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) ac[c][t4] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + t4];
+      for (int t4 = 0; t4 < 4; ++t4)
+        ac[c][t4] = (p.dbg & 4) ? f32x4{1.f, 2.f, 3.f, 4.f} : reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + t4];
     const bool low = __builtin_amdgcn_readfirstlane(cur.tr) == 1;   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
     float bq[2][16];
     auto load_b = [&](int k, float (&b)[16]) __attribute__((always_inline)) {
@@ -1898,15 +1900,17 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
           for (int c = 0; c < 4; ++c)
             acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c][e >> 2][e & 3], b, acc[c][k], 0, 0, 0);
           if ((e & 3) == 2 && e < 8) {   // two prefetch instructions per N-tile, in the k-steps every tile executes
-            prefetch_piece(piece, pfn, dqn, pmn);
+            if (!(p.dbg & 2)) prefetch_piece(piece, pfn, dqn, pmn);
             ++piece;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
-    if (low) mma(std::integral_constant<int, 8>{});
-    else mma(std::integral_constant<int, 16>{});
+    if (!(p.dbg & 1)) {
+      if (low) mma(std::integral_constant<int, 8>{});
+      else mma(std::integral_constant<int, 16>{});
+    }
     {   // shared N-tile 24: two k-steps per wave (one in the low tiles)
       const int e0 = low ? wave : 2 * wave, cnt = low ? 1 : 2;
 #pragma unroll
@@ -2501,7 +2505,7 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
   MST_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ns * 32 * 392 * 4, st));
   WgradParams wp{logmel, reinterpret_cast<const float*>(ws + T.y1), dw, B, ns, T.tr1, T.tc1,
                  e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
-                 (long long)8 * e->cfg.n_mels * frames};
+                 (long long)8 * e->cfg.n_mels * frames, 0};
   const long long total = (long long)ns * B * T.tr1 * T.tc1;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv1_wgrad: too many tiles");
   const int dbg = getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0;
@@ -2537,7 +2541,8 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   const int ns = e->cfg.n_subbands;
   MST_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ns * 64 * 1568 * 4, st));
   WgradParams wp{pool1, reinterpret_cast<const float*>(ws + T.y2), dw, B, ns, T.tr2, T.tc2,
-                 e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1};
+                 e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1,
+                 getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0};
   const long long total = (long long)ns * 4 * B * T.tr2 * T.tc2;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
   const int g = (int)std::min<long long>(e->num_cus, total);

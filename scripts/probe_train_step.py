@@ -29,7 +29,7 @@ def step():
     opt.step()
     return loss
 
-for _ in range(2):
+for _ in range(int(os.environ.get("WARMUP", 2))):
     step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
