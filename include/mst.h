@@ -205,6 +205,14 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* enc, const float* logmel, i
 int mst_encoder_train_conv2_wgrad(const mst_encoder* enc, const float* pool1, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* conv2 input gradient: the chunked fp32-MFMA convolution kernel run on d(conv2 output) with the transposed, flipped
+ * weights (64 -> 32 channels), Dropout keep-mask applied on the way out.
+ * dy2:    dev [n_sub][B][64][H1][W1]  (the NCHW-per-band tensor mst_encoder_train_backward_apply(layer 2) returns).
+ * dpool1: out dev [B][n_sub][32][H1][W1] = gradient of pool1 (feed it to backward_apply(layer 1)).
+ * drop1_mask / drop1_scale: as in mst_encoder_train_taps (NULL: no dropout).                                      */
+int mst_encoder_train_conv2_dgrad(const mst_encoder* enc, const float* dy2, int B, int frames, float* dpool1,
+                                  const unsigned char* drop1_mask, float drop1_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Augmentation chain.  Replaces AudioAugmenter.augment_stems src/mixing_utils.py:376-419 and
  * apply_spectral_tilt :421-433, apply_compression :435-447, apply_bandwidth_limit :449-456,

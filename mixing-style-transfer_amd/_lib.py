@@ -88,6 +88,8 @@ SYMBOLS = {
                                                 C.c_size_t, C.c_void_p]),
     "mst_encoder_train_conv2_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_conv2_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_float, C.c_void_p]),
     "mst_aug_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mst_aug_apply": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                 C.c_size_t, C.c_void_p]),

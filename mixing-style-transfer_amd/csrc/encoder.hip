@@ -133,6 +133,16 @@ struct CC<2, SUB> {  // Conv2d(32 -> 64, 7x7, pad 3) + MaxPool2d((4, 4)); wave t
   static constexpr int RL = 16;
 };
 
+template <int SUB>
+struct CC<3, SUB> {  // conv2 INPUT gradient: Conv2d(64 -> 32, 7x7, pad 3) of d(conv2 output) with the transposed, flipped
+                     // weights; conv1's tile geometry (2 rows x 40 columns of the 10 x 344 plane), raw output
+  static constexpr int CIN = 64, COUT = 32, NCH = 16, MT = 5, NT = 2;
+  static constexpr int WIN = 10, WPG = 2;
+  static constexpr int TROWS = 2, TCOLS = 40;
+  static constexpr int PR = TROWS + 6, PC = TCOLS + 6;
+  static constexpr int RL = 64;
+};
+
 struct ConvParams {
   const float* in;
   const float* wfrag;  // [nsub][NCH][WBP]   B fragments: [tap][nt][lane], zero padded to the chunk pitch
@@ -155,6 +165,9 @@ struct ConvParams {
   double* stats;
   const float* bias;          // [nsub][COUT]
   int raw_rows, raw_cols;     // valid extent of the convolution output plane
+  // MODE 2 (conv2 input gradient): raw output to out[clip][band][COUT][raw_rows][raw_cols], times the Dropout keep-mask
+  const unsigned char* mask;
+  float mask_scale;
 };
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
@@ -192,7 +205,8 @@ template <int LAYER, int SUB, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) {
   using C = CC<LAYER, SUB>;
   using GEO = ConvGeom<LAYER, SUB>;
-  static_assert(MODE == 0 || LAYER == 2, "raw mode: conv2 here, conv1 in conv1_resident_kernel");
+  static_assert(MODE == 0 || (MODE == 1 && LAYER == 2) || (MODE == 2 && LAYER == 3), "raw modes: conv2 forward, conv2 dgrad");
+  constexpr bool GEO1 = LAYER == 1 || LAYER == 3;   // 2 x 40 tiles, pooling-window accumulator order
   constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
   constexpr int WBP = GEO::WBP, PATCH = GEO::PATCH, NWF = GEO::NWF, NPF = GEO::NPF, NCV = GEO::NCV;
   constexpr int NPIECE = NPF + NWF, PPT = (NPIECE + 48) / 49;  // prefetch pieces, pieces issued per tap
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     int dr, wc;
-    if constexpr (LAYER == 1) {
+    if constexpr (GEO1) {
       const int e = 4 * t + areg, wv = e / C::WIN, pos = e % C::WIN;
       dr = pos / 5;
       wc = 5 * (C::WPG * ag + wv) + pos % 5;
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
   auto prefetch_setup = [&](int q, const Tile& t) __attribute__((always_inline)) {
     const int chunk = q % NCH;
     nwsrc = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)t.band * NCH + chunk) * WBP);
-    nrow0 = (LAYER == 1 ? C::TROWS * t.tr : 8 * t.tr) - 3;
+    nrow0 = (GEO1 ? C::TROWS * t.tr : 8 * t.tr) - 3;
     ncol0 = C::TCOLS * t.tc - 3;
     nvalid = t.valid;
     nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff + (size_t)(4 * chunk) * p.in_cstride;
@@ -381,6 +395,28 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
             if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
           dst[t] = v;
+        }
+      }
+    }
+    if (MODE == 2 && chunk == NCH - 1 && cur.valid) {
+      // conv2 input gradient: raw values to the pool1-shaped tensor, Dropout mask applied on the way out
+      const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = n * 16 + j;
+        float* ob = p.out + (((size_t)cur.clip * p.nsub + cur.band) * C::COUT + ch) * (size_t)p.raw_rows * p.raw_cols;
+        const unsigned char* mb = p.mask ? p.mask + (((size_t)cur.clip * p.nsub + cur.band) * C::COUT + ch) * (size_t)p.raw_rows * p.raw_cols
+                                         : nullptr;
+#pragma unroll
+        for (int e = 0; e < 4 * MT; ++e) {
+          const int wv = e / C::WIN, pos = e % C::WIN;
+          const int row = C::TROWS * cur.tr + pos / 5, col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
+          if (row < p.raw_rows && col < p.raw_cols) {
+            const size_t o = (size_t)row * p.raw_cols + col;
+            float v = acc[e >> 2][n][e & 3];
+            if (mb) v = mb[o] ? v * p.mask_scale : 0.f;
+            ob[o] = v;
+          }
         }
       }
     }
@@ -1160,6 +1196,7 @@ struct mst_encoder {
   int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3, 3 conv1 + conv2 plain f16 (amp)
   // un-folded parameters for the training forward (batch-statistics BatchNorm)
   float *c1b = nullptr, *bn1w = nullptr, *bn1b = nullptr, *c2b = nullptr, *bn2w = nullptr, *bn2b = nullptr;
+  float* w2dfrag = nullptr;   // conv2 input-gradient weight fragments [nsub][16][WBP] (refreshed by update_trunk_params)
 };
 
 namespace {
@@ -1958,6 +1995,23 @@ __global__ void conv_fragments_kernel(const float* w, float* f, int nsub, int co
   f[((size_t)b * nch + ch) * wchp + ((size_t)tap * nt + n) * 64 + lane] = w[(((size_t)b * cout + co) * cin + ci) * 49 + tap];
 }
 
+// conv2 weights [nsub][64 co][32 ci][49] -> B fragments of the input-gradient convolution (64 -> 32, flipped taps):
+// f[band][chunk c][tap][nt][lane] = W2[co = 4 c + (lane >> 4)][ci = 16 nt + (lane & 15)][48 - tap]
+__global__ void dgrad_fragments_kernel(const float* w, float* f, int nsub, int wchp) {
+  const long long total = (long long)nsub * 16 * 49 * 2 * 64;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  long long r = i >> 6;
+  const int n = (int)(r % 2);
+  r /= 2;
+  const int tap = (int)(r % 49);
+  r /= 49;
+  const int ch = (int)(r % 16), b = (int)(r / 16);
+  const int co = 4 * ch + (lane >> 4), ci = n * 16 + (lane & 15);
+  f[((size_t)b * 16 + ch) * wchp + ((size_t)tap * 2 + n) * 64 + lane] = w[(((size_t)b * 64 + co) * 32 + ci) * 49 + (48 - tap)];
+}
+
 template <int LAYER, int SUB>
 hipError_t launch_conv(const ConvParams& cp, int grid, hipStream_t st) {
   using GEO = ConvGeom<LAYER, SUB>;
@@ -2075,6 +2129,18 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   UPP(att0_b, w->att0_b, A); UPP(att2_w, w->att2_w, A); UPP(proj_b, w->proj_b, E);
   UPP(c1b, w->conv1_b, ns * 32); UPP(bn1w, w->bn1_w, ns * 32); UPP(bn1b, w->bn1_b, ns * 32);
   UPP(c2b, w->conv2_b, ns * 64); UPP(bn2w, w->bn2_w, ns * 64); UPP(bn2b, w->bn2_b, ns * 64);
+  if (!rc) {   // input-gradient fragments of conv2, built on the device from a temporary copy of the weights
+    float* tmp = nullptr;
+    rc = mst::upload(&tmp, w->conv2_w, (size_t)ns * 64 * 32 * 49);
+    if (!rc && hipMalloc(&e->w2dfrag, (size_t)ns * 16 * ConvGeom<3, 2>::WBP * sizeof(float)) != hipSuccess) rc = MST_ENOMEM;
+    if (!rc) {
+      (void)hipMemset(e->w2dfrag, 0, (size_t)ns * 16 * ConvGeom<3, 2>::WBP * sizeof(float));
+      const long long t3 = (long long)ns * 16 * 49 * 2 * 64;
+      hipLaunchKernelGGL(dgrad_fragments_kernel, dim3((unsigned)((t3 + 255) / 256)), dim3(256), 0, 0, tmp, e->w2dfrag, ns, ConvGeom<3, 2>::WBP);
+      (void)hipDeviceSynchronize();
+    }
+    (void)hipFree(tmp);
+  }
 #undef UP
 #undef UPP
   if (rc) {
@@ -2089,7 +2155,7 @@ void mst_encoder_destroy(mst_encoder* e) {
   if (!e) return;
   float* ptrs[] = {e->w1frag, e->w2frag, e->s1, e->t1, e->s2, e->t2, e->w0t, e->b0, e->w3t, e->b3, e->hwt,
                    e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b, e->c1b, e->bn1w, e->bn1b, e->c2b,
-                   e->bn2w, e->bn2b};
+                   e->bn2w, e->bn2b, e->w2dfrag};
   for (float* q : ptrs) (void)hipFree(q);
   (void)hipFree(e->w1frag16);
   (void)hipFree(e->w2frag16);
@@ -2483,6 +2549,9 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
                        ConvGeom<1, 2>::WBP);
     hipLaunchKernelGGL(conv_fragments_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, st, conv2_w, e->w2frag, ns, 64, 32,
                        ConvGeom<2, 2>::WBP);
+    const long long t3 = (long long)ns * 16 * 49 * 2 * 64;
+    hipLaunchKernelGGL(dgrad_fragments_kernel, dim3((unsigned)((t3 + 255) / 256)), dim3(256), 0, st, conv2_w, e->w2dfrag, ns,
+                       ConvGeom<3, 2>::WBP);
     MST_HIP_CHECK(hipGetLastError());
   }
   const struct { float* dst; const float* src; int n; } cp[] = {
@@ -2547,6 +2616,38 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
   const int g = (int)std::min<long long>(e->num_cus, total);
   hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
+  MST_HIP_CHECK(hipGetLastError());
+  return MST_OK;
+}
+
+int mst_encoder_train_conv2_dgrad(const mst_encoder* e, const float* dy2, int B, int frames, float* dpool1,
+                                  const unsigned char* drop1_mask, float drop1_scale, void* stream) {
+  MST_REQUIRE(e && dy2 && dpool1, "mst_encoder_train_conv2_dgrad: NULL argument");
+  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20, "mst_encoder_train_conv2_dgrad: bad arguments");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ns = e->cfg.n_subbands, H1 = e->H1, W1 = frames / 5;
+  ConvParams cp{};
+  cp.in = dy2, cp.wfrag = e->w2dfrag, cp.out = dpool1, cp.B = B, cp.nsub = ns;
+  cp.in_rows = H1, cp.in_cols = W1;
+  cp.in_cstride = H1 * W1;                       // dy2 is [band][B][64][H1][W1]
+  cp.in_bandoff = B * 64 * H1 * W1;
+  cp.in_clipstride = (long long)64 * H1 * W1;
+  cp.out_rows = H1, cp.out_cols = W1;
+  cp.tiles_r = (H1 + 1) / 2, cp.tiles_c = (W1 + 39) / 40;
+  cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+  cp.raw_rows = H1, cp.raw_cols = W1, cp.mask = drop1_mask, cp.mask_scale = drop1_scale;
+  MST_REQUIRE((long long)cp.in_bandoff * ns < (1LL << 31), "mst_encoder_train_conv2_dgrad: batch too large for 32-bit band offsets");
+  const int g = std::min(e->num_cus, ns * cp.sets_per_band);
+  using GEO = ConvGeom<3, 2>;
+  const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<3, 2, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 dgrad attribute failed: %s", hipGetErrorString(err));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_kernel<3, 2, 2>), dim3(g), dim3(kConvThreads), lds, st, cp);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }

@@ -274,6 +274,16 @@ class HipEncoder:
                        "mst_encoder_train_conv1_wgrad")
         return dw
 
+    def conv2_dgrad(self, dy2, B, frames, mask=None, drop_p=0.0):
+        """gradient of pool1 (B, n_sub, 32, H1, W1) from dy2 (n_sub, B, 64, H1, W1): `mst_encoder_train_conv2_dgrad`."""
+        L = _lib.lib()
+        out = torch.empty(B, self.n_sub, 32, self.split // 2, frames // 5, device=dy2.device)
+        with torch.cuda.device(dy2.device):
+            _lib.check(L.mst_encoder_train_conv2_dgrad(self._h, _lib.dptr(dy2), B, frames, _lib.dptr(out), _lib.dptr(mask),
+                                                       1.0 / (1.0 - drop_p) if mask is not None else 1.0,
+                                                       _lib.stream_ptr(dy2.device)), "mst_encoder_train_conv2_dgrad")
+        return out
+
     def conv2_wgrad(self, pool1, B, frames):
         """conv2 weight gradient (n_sub, 64, 32, 7, 7) from the accumulator-order d(conv2 output) in the workspace."""
         L = _lib.lib()
@@ -354,6 +364,7 @@ _CONV1_WGRAD_MIOPEN = os.environ.get("MST_CONV1_WGRAD", "") == "miopen"
 # the hand-written conv2 weight gradient is correct (same parity test) and within 20 % of the library's (8.8 vs 7.4 ms):
 # opt-in (MST_CONV2_WGRAD=hip) until it wins
 _CONV2_WGRAD_MIOPEN = os.environ.get("MST_CONV2_WGRAD", "miopen") != "hip"
+_CONV2_DGRAD_MIOPEN = os.environ.get("MST_CONV2_DGRAD", "") == "miopen"
 
 
 class _HipTrunk(torch.autograd.Function):
@@ -396,22 +407,27 @@ class _HipTrunk(torch.autograd.Function):
         dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr)
         mark("apply_bwd2")
         gi, gw2, gb2 = [], [], []
-        native_w2 = not _CONV2_WGRAD_MIOPEN
-        for i in range(ns):
-            a, b, c = bw(dy2[i], p1[:, i].contiguous(), c2w[i], [64], [1, 1], [3, 3], [1, 1], False, [0, 0], 1,
-                         [True, not native_w2, not native_w2])
-            gi.append(a), gw2.append(b), gb2.append(c)
-        mark("conv2_dgrad(miopen)" if native_w2 else "conv2_bwd(miopen)")
+        native_w2, native_d2 = not _CONV2_WGRAD_MIOPEN, not _CONV2_DGRAD_MIOPEN
+        if not (native_w2 and native_d2):
+            for i in range(ns):
+                a, b, c = bw(dy2[i], p1[:, i].contiguous(), c2w[i], [64], [1, 1], [3, 3], [1, 1], False, [0, 0], 1,
+                             [not native_d2, not native_w2, not native_w2])
+                gi.append(a), gw2.append(b), gb2.append(c)
+            mark("conv2 library part")
         if native_w2:   # hand-written fp32-MFMA weight gradient on dy2 in accumulator order; bias gradient == 0
             gw2 = enc.conv2_wgrad(p1, B, Fr)
             gb2 = torch.zeros(ns, 64, device=logmel.device)
             mark("conv2_wgrad")
         else:
             gw2, gb2 = torch.stack(gw2), torch.stack(gb2)
-        dp1 = torch.stack(gi, 1)
-        if mask is not None:
-            dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
-        mark("stack+mask")
+        if native_d2:   # hand-written input gradient (chunked fp32-MFMA conv on dy2, Dropout mask fused)
+            dp1 = enc.conv2_dgrad(dy2, B, Fr, mask, ctx.drop_p)
+            mark("conv2_dgrad")
+        else:
+            dp1 = torch.stack(gi, 1)
+            if mask is not None:
+                dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
+            mark("stack+mask")
         if _CONV1_WGRAD_MIOPEN:   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (for A/B checks)
             dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
             mark("apply_bwd1")
