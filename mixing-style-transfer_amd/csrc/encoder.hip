@@ -1782,9 +1782,13 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
   const int G = gridDim.x, wg = mst::xcd_remap(blockIdx.x, G);
-  const int tpc = p.B * p.tiles_r * p.tiles_c;           // tiles per (band, chunk)
-  const int total = p.nsub * NCH * tpc;
-  const int s_begin = (int)((long long)wg * total / G), s_end = (int)((long long)(wg + 1) * total / G);
+  // work = (band, tile) pairs, dealt in contiguous ranges to GROUPS of 4 workgroups; the 4 members of a group walk the
+  // same range, one input-channel chunk each, side by side on one XCD: the tile's dy is fetched from HBM once and
+  // found in L2 by the other three
+  const int tpc = p.B * p.tiles_r * p.tiles_c;           // tiles per band
+  const int total = p.nsub * tpc;
+  const int my_chunk = wg & (NCH - 1), rg = wg >> 2, RG = G >> 2;
+  const int s_begin = (int)((long long)rg * total / RG), s_end = (int)((long long)(rg + 1) * total / RG);
   if (s_begin >= s_end) return;
 
   const int goff = (4 * (g >> 1)) * PC + 4 * (g & 1);
@@ -1803,10 +1807,9 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   };
   auto decode = [&](int s) __attribute__((always_inline)) {
     Item t;
-    t.band = s / (NCH * tpc);
-    int r = s - t.band * NCH * tpc;
-    t.chunk = r / tpc;
-    r -= t.chunk * tpc;
+    t.band = s / tpc;
+    int r = s - t.band * tpc;
+    t.chunk = my_chunk;
     t.clip = r / (p.tiles_r * p.tiles_c);
     r -= t.clip * p.tiles_r * p.tiles_c;
     t.tr = r / p.tiles_c, t.tc = r - t.tr * p.tiles_c;
@@ -1817,10 +1820,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
       t.tc = 0;
       if (++t.tr == p.tiles_r) {
         t.tr = 0;
-        if (++t.clip == p.B) {
-          t.clip = 0;
-          if (++t.chunk == NCH) t.chunk = 0, ++t.band;
-        }
+        if (++t.clip == p.B) t.clip = 0, ++t.band;
       }
     }
     return t;
@@ -2612,9 +2612,9 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   WgradParams wp{pool1, reinterpret_cast<const float*>(ws + T.y2), dw, B, ns, T.tr2, T.tc2,
                  e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1,
                  getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0};
-  const long long total = (long long)ns * 4 * B * T.tr2 * T.tc2;
+  const long long total = (long long)ns * B * T.tr2 * T.tc2;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
-  const int g = (int)std::min<long long>(e->num_cus, total);
+  const int g = (int)std::min<long long>(e->num_cus & ~3, 4 * total);   // groups of 4 workgroups (one per input-channel chunk)
   hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
