@@ -345,6 +345,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    const bool low_rows = MODE == 1 && LAYER == 2 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
+                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;   // wave-uniform
     // 49 taps x (MT A-fragments, NT B-fragments, MT*NT MFMAs); the fragments of tap+1 are read from LDS and PPT
     // pieces of the next chunk are fetched from global memory while the MFMAs of this tap are in flight
     {
@@ -362,7 +364,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
         for (int i = 0; i < MT * NT; ++i) {
           const int t = i / NT, n = i % NT;
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+          // training forward, second tile row of conv2 (output rows 8..15 of 10): M-tiles 2, 3 are rows 10.. -> skipped
+          if (!(MODE == 1 && LAYER == 2 && t >= 2 && low_rows))
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
           if (tap + 1 < 49) {
             if (i < NT) b[nx][i] = wb[((tap + 1) * NT + i) * 64 + lane];   // B first: needed by the next tap's MFMA 0
             else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];

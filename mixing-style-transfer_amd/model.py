@@ -6,9 +6,11 @@ Forward paths
   * inference (`model.eval()` or `torch.no_grad()`): hand-written HIP kernels through libmst.so --
     stage A (STFT -> mel -> log) and stage B (FiLM MLP, band-split conv stack, attention pooling).
     This is the product path and the one every parity claim refers to.
-  * training with autograd (`model.train()` and grad enabled): stage A still runs in HIP (the waveform needs
-    no gradient); the encoder runs on PyTorch-ROCm ops so that autograd, train-mode BatchNorm statistics and
-    Dropout behave as in the reference.  HIP backward kernels are the next row of SURVEY.md section 8(f).
+  * training with autograd (`model.train()` and grad enabled, `train_backend = "hip"`, the default): stage A in HIP (the
+    waveform needs no gradient); the conv trunk -- train-mode BatchNorm forward, Dropout, and the whole backward (pool /
+    ReLU / FiLM / BatchNorm, conv2 input gradient, both conv weight gradients) -- in hand-written HIP kernels behind one
+    autograd Function (`_HipTrunk`); the FiLM MLP and the attention head (0.4 % of the flops) stay torch modules.
+    `train_backend = "torch"` runs the whole encoder on PyTorch-ROCm autograd (the path the gradients are tested against).
 """
 import ctypes as C
 
@@ -361,18 +363,17 @@ class HipEncoder:
 
 _TRAIN_TIMING = bool(os.environ.get("MST_TRAIN_TIMING"))
 _CONV1_WGRAD_MIOPEN = os.environ.get("MST_CONV1_WGRAD", "") == "miopen"
-# the hand-written conv2 weight gradient is correct (same parity test) and within 20 % of the library's (8.8 vs 7.4 ms):
-# opt-in (MST_CONV2_WGRAD=hip) until it wins
-_CONV2_WGRAD_MIOPEN = os.environ.get("MST_CONV2_WGRAD", "miopen") != "hip"
+# library (MIOpen, via aten.convolution_backward) versions of the three convolution gradients, kept for A/B checks only
+_CONV2_WGRAD_MIOPEN = os.environ.get("MST_CONV2_WGRAD", "") == "miopen"
 _CONV2_DGRAD_MIOPEN = os.environ.get("MST_CONV2_DGRAD", "") == "miopen"
 
 
 class _HipTrunk(torch.autograd.Function):
     """The 11 x [conv -> BatchNorm(batch statistics) -> FiLM -> ReLU -> max-pool] x 2 trunk for training.
     Forward: libmst.so (`mst_encoder_forward_train`, raw conv outputs kept).  Backward: pool / ReLU / FiLM / BatchNorm in
-    libmst.so (`mst_encoder_train_backward_apply`); the convolution weight / input gradients are still taken from
-    PyTorch-ROCm (`aten.convolution_backward`, MIOpen) per sub-band -- the hand-written wgrad / dgrad kernels are the
-    remaining piece of SURVEY 8 f1."""
+    libmst.so (`mst_encoder_train_backward_apply`), conv2 input gradient (`mst_encoder_train_conv2_dgrad`) and both weight
+    gradients (`mst_encoder_train_conv{1,2}_wgrad`) as hand-written fp32-MFMA kernels.  MST_CONV1_WGRAD / MST_CONV2_WGRAD /
+    MST_CONV2_DGRAD=miopen switch single pieces back to `aten.convolution_backward` for A/B checks."""
     last_timing = None
 
     @staticmethod
