@@ -44,6 +44,10 @@ def parse():
                          "extra measurements, not the contract line: baseline_sh = the reference's scripts/train_baseline.sh "
                          "(2048/512/80 mels, 16/8, 512-d); config5 = BASELINE configs[4] shapes (256 mels, 24 sub-bands; "
                          "use --seconds 30 --triplets 8), forward only, fp32")
+    ap.add_argument("--train", action="store_true",
+                    help="extra measurement, not the contract line: a full TRAINING step (stage A, encoder forward + backward "
+                         "with train-mode BatchNorm and Dropout, InfoNCE forward + backward, AdamW) instead of the forward path")
+    ap.add_argument("--train-backend", choices=["hip", "torch"], default="hip")
     ap.add_argument("--ingest", choices=["resident", "f32", "pcm16"], default="resident",
                     help="resident (default, the contract: inputs in HBM before timing) | f32 | pcm16: every step's batch "
                          "comes from pinned host memory over PCIe (double-buffered, overlapped); PCIe-inclusive rate")
@@ -194,6 +198,54 @@ def main():
             if a.aug:   # host RNG work for the NEXT step overlaps this step's kernels (a data-loader worker's job)
                 pending.append(augm.draw_decisions(B // 3))
             return crit(emb, labels)
+
+    if a.train:   # training step: same data, same metric unit; reported with its own workload string
+        model.train()
+        model.train_backend = a.train_backend
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+        crit_t = InfoNCELoss(0.1, gather=world > 1)
+
+        def train_step():
+            with torch.no_grad():
+                feats, logmel = fe.features_and_logmel(stems)
+            emb = model.forward_from_logmel(logmel, feats)
+            loss = crit_t(emb, labels)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            if world > 1:   # data-parallel: sum the parameter gradients (see loss.InfoNCELoss)
+                for prm in model.parameters():
+                    if prm.grad is not None:
+                        dist.all_reduce(prm.grad)
+            opt.step()
+            return loss
+        for _ in range(max(a.warmup, 5)):
+            train_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = train_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "triplets/sec (10 s @ 44.1 kHz, 4-stem, bs=24)", "value": round(world * a.triplets * a.steps / t.item(), 3),
+                "unit": "triplets/s", "n_gpus": world, "steps": a.steps, "warmup": max(a.warmup, 5),
+                "ms_per_step": round(t.item() / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"NOT THE CONTRACT LINE -- full TRAINING step ({a.train_backend} encoder backend): HIP stage A, "
+                                       "encoder forward + backward (train-mode BatchNorm, Dropout 0.3), InfoNCE forward + backward, "
+                                       f"AdamW; {a.triplets} triplets = {B} clips of {a.seconds:.0f} s per GPU",
+                           "clips_per_gpu": B, "train_backend": a.train_backend, "loss": float(loss),
+                           "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     for _ in range(a.warmup):
         step(False)
