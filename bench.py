@@ -241,7 +241,7 @@ def main():
                 "config": {"workload": f"NOT THE CONTRACT LINE -- full TRAINING step ({a.train_backend} encoder backend): HIP stage A, "
                                        "encoder forward + backward (train-mode BatchNorm, Dropout 0.3), InfoNCE forward + backward, "
                                        f"AdamW; {a.triplets} triplets = {B} clips of {a.seconds:.0f} s per GPU",
-                           "clips_per_gpu": B, "train_backend": a.train_backend, "loss": float(loss),
+                           "clips_per_gpu": B, "train_backend": a.train_backend, "loss": float(loss.detach()),
                            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}}), flush=True)
         if world > 1:
             dist.destroy_process_group()

@@ -385,7 +385,8 @@ class _HipTrunk(torch.autograd.Function):
         if drop_p > 0.0:
             mask = (torch.rand(B, enc.n_sub, 32, enc.split // 2, W1, device=logmel.device) >= drop_p).to(torch.uint8)
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p)
-        ctx.enc, ctx.drop_p, ctx.dims = enc, drop_p, (B, Fr)
+        enc._train_gen = getattr(enc, "_train_gen", 0) + 1   # the saved activations live in the encoder's workspace
+        ctx.enc, ctx.drop_p, ctx.dims, ctx.gen = enc, drop_p, (B, Fr), enc._train_gen
         ctx.save_for_backward(logmel, t["pool1"], c1w, c2w, mask)
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
         return t["pool_in"], t["bn1"], t["bn2"]
@@ -393,6 +394,11 @@ class _HipTrunk(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpool_in, _d1, _d2):
         enc, (B, Fr) = ctx.enc, ctx.dims
+        if ctx.gen != enc._train_gen:
+            raise RuntimeError("HIP training trunk: backward() of an older forward pass -- the saved activations live in one "
+                               "workspace per model, so every forward must be followed by its backward before the next "
+                               "forward (gradient accumulation over micro-batches is fine); use train_backend='torch' "
+                               "for graphs that keep several forward passes alive")
         logmel, p1, c1w, c2w, mask = ctx.saved_tensors
         ns, ov, sp = enc.n_sub, enc.overlap, enc.split
         bw = torch.ops.aten.convolution_backward

@@ -325,6 +325,12 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules():
     for (n, ba), (_, bb) in zip(model.named_buffers(), ref.named_buffers()):
         if "running" in n:
             close(ba.cpu(), bb.cpu(), 2e-4)
+    # two forward passes alive at once are refused loudly (one activation workspace per model)
+    o1 = model(stems, feats).sum()
+    o2 = model(stems, feats).sum()
+    o2.backward()
+    with pytest.raises(RuntimeError, match="older forward"):
+        o1.backward()
     # dropout after the first pooling: every element is either dropped or scaled by 1 / (1 - p)
     enc = model._hip_train
     with torch.no_grad():
