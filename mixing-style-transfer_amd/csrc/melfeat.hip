@@ -1,19 +1,21 @@
-// Stage A: waveform -> windowed real FFT -> |X|^2 -> sparse HTK mel -> log-mel + mixing-feature
+// Stage A: waveform -> windowed FFT -> |X|^2 -> sparse HTK mel -> log-mel + mixing-feature
 // partial sums, and the finalise kernel that turns the partials into the 64-d feature vector.
 //
 // Replaces (reference barry-mir/mixing-style-transfer): torchaudio MelSpectrogram as called at
 // src/mixing_utils.py:159,280 and src/model.py:58-65; MixingFeatureExtractor src/mixing_utils.py:71-357.
 //
 // Kernel shape (gfx950, wave64):
-//   * one workgroup = 4 waves = one (clip, run of frames); blockIdx is XCD-remapped so the runs of
+//   * one workgroup = one (clip, run of ceil(F/32) frames), all 8 channels; blockIdx is XCD-remapped so the runs of
 //     one clip sit on one XCD (overlapping frame reads and partial output lines meet in one L2);
-//   * one wave = one real n_fft-point FFT at a time, as an n_fft/2-point complex Stockham FFT
-//     held in registers (radix-8/4 butterflies), exchanged through a wave-private LDS scratch
-//     between passes; twiddles / window / sparse mel weights live in LDS tables;
-//   * each sample is read from HBM once (frames overlap 4x, re-reads hit L1/L2), each log-mel
-//     value is written once, staged through an LDS tile so that stores are frame-contiguous;
-//   * all feature statistics (per-band dB sums, flatness sums, inter-stem masking, waveform
-//     moments) are accumulated in registers in the same pass and reduced per workgroup.
+//   * melfeat_spw_kernel (standard configuration): 12 waves, 3 per stem; a wave transforms the L and R channel of
+//     one frame as ONE n_fft-point complex Stockham FFT held in registers (radix-8/4 butterflies), exchanged
+//     through a wave-private LDS scratch between passes; twiddles / window / sparse mel weights live in LDS tables;
+//     melfeat_kernel (any hop, odd T, 256 mels, n_fft 512 / 2048): 8 waves, two frames per wave;
+//   * each sample is read from HBM once (frames overlap 4x, re-reads hit L1/L2), each log-mel value is written
+//     once, staged through an LDS tile so that stores are frame-contiguous;
+//   * all feature statistics (per-band dB sums, flatness sums, inter-stem masking, waveform moments) are
+//     accumulated in registers in the same pass and reduced per workgroup.
+// The sample type is a template parameter (float, or int16 PCM converted in the load).
 #include "common.h"
 #include "fft_wave.h"
 
