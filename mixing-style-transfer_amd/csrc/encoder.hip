@@ -205,7 +205,7 @@ template <int LAYER, int SUB, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) {
   using C = CC<LAYER, SUB>;
   using GEO = ConvGeom<LAYER, SUB>;
-  static_assert(MODE == 0 || (MODE == 1 && LAYER == 2) || (MODE == 2 && LAYER == 3), "raw modes: conv2 forward, conv2 dgrad");
+  static_assert(MODE == 0 || (MODE == 1 && LAYER != 3) || (MODE == 2 && LAYER == 3), "raw modes: forward layers, conv2 dgrad");
   constexpr bool GEO1 = LAYER == 1 || LAYER == 3;   // 2 x 40 tiles, pooling-window accumulator order
   constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
   constexpr int WBP = GEO::WBP, PATCH = GEO::PATCH, NWF = GEO::NWF, NPF = GEO::NPF, NCV = GEO::NCV;
@@ -395,7 +395,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] += b;
-            const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
+            int row, col;
+            if constexpr (LAYER == 1) {
+              const int e = 4 * t + r, wv = e / C::WIN, pos = e % C::WIN;
+              row = C::TROWS * cur.tr + pos / 5, col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
+            } else {
+              row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
+            }
             if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
           dst[t] = v;
@@ -1301,9 +1307,9 @@ struct ApplyParams {
   long long units;   // B * nsub * tiles_r * tiles_c * NT * 64
 };
 
-template <int LAYER>
+template <int LAYER, int SUB>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
-  using C = CC<LAYER, 2>;
+  using C = CC<LAYER, SUB>;
   constexpr int NT = C::NT, NV = 4 * C::MT;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   if (u >= p.units) return;
@@ -1373,9 +1379,9 @@ struct ApplyBwdParams {
   int chunks;              // pass A: blocks per (clip, band)
 };
 
-template <int LAYER>
+template <int LAYER, int SUB>
 __device__ __forceinline__ void unit_geometry(int tr, int tc, int g, int e, int& row, int& col) {
-  using C = CC<LAYER, 2>;
+  using C = CC<LAYER, SUB>;
   if constexpr (LAYER == 1) {
     const int wv = e / C::WIN, pos = e % C::WIN;
     row = C::TROWS * tr + pos / 5;
@@ -1387,10 +1393,10 @@ __device__ __forceinline__ void unit_geometry(int tr, int tc, int g, int e, int&
 }
 
 // df for the NV values of one lane-unit: zero except at the arg-max of every pooling window with a positive maximum
-template <int LAYER>
-__device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v)[4 * CC<LAYER, 2>::MT], float2 ac, int clip,
-                                        int band, int ch, int tr, int tc, int g, float (&df)[4 * CC<LAYER, 2>::MT]) {
-  using C = CC<LAYER, 2>;
+template <int LAYER, int SUB>
+__device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v)[4 * CC<LAYER, SUB>::MT], float2 ac, int clip,
+                                        int band, int ch, int tr, int tc, int g, float (&df)[4 * CC<LAYER, SUB>::MT]) {
+  using C = CC<LAYER, SUB>;
   constexpr int NV = 4 * C::MT;
 #pragma unroll
   for (int e = 0; e < NV; ++e) df[e] = 0.f;
@@ -1414,9 +1420,9 @@ __device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v
   }
 }
 
-template <int LAYER>
+template <int LAYER, int SUB>
 __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdParams p) {   // grid (chunks, B*nsub)
-  using C = CC<LAYER, 2>;
+  using C = CC<LAYER, SUB>;
   constexpr int NT = C::NT, NV = 4 * C::MT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int clip = blockIdx.y / p.nsub, band = blockIdx.y % p.nsub;
@@ -1443,7 +1449,7 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
     }
-    unit_df<LAYER>(p, v, ac, clip, band, ch, tr, tc, g, df);
+    unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
       const float zh = (v[e] - ms.x) * ms.y;
@@ -1467,9 +1473,9 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
   }
 }
 
-template <int LAYER>
+template <int LAYER, int SUB>
 __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams p, long long units) {
-  using C = CC<LAYER, 2>;
+  using C = CC<LAYER, SUB>;
   constexpr int NT = C::NT, NV = 4 * C::MT;
   const long long u = (long long)blockIdx.x * 256 + threadIdx.x;
   if (u >= units) return;
@@ -1494,7 +1500,7 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
   }
-  unit_df<LAYER>(p, v, ac, clip, band, ch, tr, tc, g, df);
+  unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
   const float k = gb * ms.y;
   if (p.dy_acc != nullptr) {   // in place, accumulator order (operand layout of the hand-written weight gradient); 0 outside
     f32x4* dst = reinterpret_cast<f32x4*>(p.dy_acc + (size_t)u * NV);
@@ -1505,7 +1511,7 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
       for (int r = 0; r < 4; ++r) {
         const int e = 4 * t + r;
         int row, col;
-        unit_geometry<LAYER>(tr, tc, g, e, row, col);
+        unit_geometry<LAYER, SUB>(tr, tc, g, e, row, col);
         const float zh = (v[e] - ms.x) * ms.y;
         q[r] = (row < p.rows && col < p.cols) ? k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2) : 0.f;
       }
@@ -1517,7 +1523,7 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
     int row, col;
-    unit_geometry<LAYER>(tr, tc, g, e, row, col);
+    unit_geometry<LAYER, SUB>(tr, tc, g, e, row, col);
     if (row < p.rows && col < p.cols) {
       const float zh = (v[e] - ms.x) * ms.y;
       dyb[(size_t)row * p.cols + col] = k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2);
@@ -1920,7 +1926,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
 #pragma unroll
       for (int t4 = 0; t4 < 4; ++t4)
         ac[c][t4] = (p.dbg & 4) ? f32x4{1.f, 2.f, 3.f, 4.f} : reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + t4];
-    const bool low = __builtin_amdgcn_readfirstlane(cur.tr) == 1;   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
+    const bool low = 8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.in_rows;   // at most rows 8tr, 8tr+1 exist   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
     float bq[2][16];
     auto load_b = [&](int k, float (&b)[16]) __attribute__((always_inline)) {
 #pragma unroll
@@ -2337,7 +2343,8 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   TrainLayout T{};
   T.base = ws_layout(e, B, frames);
   const int ns = e->cfg.n_subbands;
-  T.tr1 = e->H1, T.tc1 = (frames + 39) / 40;                 // conv1 tiles: 2 rows x 40 columns, ALL columns (statistics)
+  const int tcols1 = e->sub == 2 ? 40 : 80;                    // conv1 tiles: SUB rows x 40 / 80 columns, ALL columns (statistics)
+  T.tr1 = e->H1, T.tc1 = (frames + tcols1 - 1) / tcols1;
   T.tr2 = (e->H1 + 7) / 8, T.tc2 = (T.base.W1 + 7) / 8;      // conv2 tiles: 8 x 8, ALL rows
   size_t o = T.base.total;
   auto take = [&](size_t bytes) {
@@ -2357,14 +2364,13 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
 }  // namespace
 
 size_t mst_encoder_train_workspace_bytes(const mst_encoder* e, int B, int frames) {
-  if (!e || B <= 0 || frames < 20 || e->sub != 2) return 0;
+  if (!e || B <= 0 || frames < 20) return 0;
   return train_layout(e, B, frames).total;
 }
 
 int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
                               const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && logmel && (feats || (taps && taps->film_in)), "mst_encoder_forward_train: NULL argument");
-  MST_REQUIRE(e->sub == 2, "mst_encoder_forward_train: needs the default 20-mel sub-bands (pool height 2)");
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward_train: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
@@ -2411,16 +2417,29 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     cp.yraw = y1, cp.stats = stats1, cp.bias = e->c1b, cp.raw_rows = e->cfg.split_size, cp.raw_cols = frames;
     const int g = std::min(grid, ns * cp.sets_per_band);
-    using C = CC<1, 2>;
-    constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (train) attribute failed: %s", hipGetErrorString(err));
-      attr_set = true;
+    if (e->sub == 2) {
+      using C = CC<1, 2>;
+      constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (train) attribute failed: %s", hipGetErrorString(err));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv1_resident_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
+    } else {   // 10..19-mel sub-bands (pool height 1): the chunked kernel with the raw epilogue
+      using GEO = ConvGeom<1, 1>;
+      const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<1, 1, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (train) attribute failed: %s", hipGetErrorString(err));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv_kernel<1, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     }
-    hipLaunchKernelGGL((conv1_resident_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     MST_HIP_CHECK(hipGetLastError());
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn1);
     FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, (double)B * e->cfg.split_size * frames, e->cfg.bn_eps,
@@ -2428,7 +2447,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
     ApplyParams ap{y1, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
                    B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64};
-    hipLaunchKernelGGL((apply_kernel<1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
+    if (e->sub == 2) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
+    else hipLaunchKernelGGL((apply_kernel<1, 1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
   {   // conv2 raw + statistics (all 10 rows: rows 8, 9 never reach MaxPool(4,4) but count in the batch statistics)
@@ -2458,7 +2478,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
     ApplyParams ap{y2, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
-    hipLaunchKernelGGL((apply_kernel<2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
+    hipLaunchKernelGGL((apply_kernel<2, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
   if (emb) {   // attention pooling head (emb == NULL: the caller runs its own head on pool_in)
@@ -2491,7 +2511,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && dpool && dfilm && dbn, "mst_encoder_train_backward_apply: NULL argument");
 
-  MST_REQUIRE(e->sub == 2 && (layer == 1 || layer == 2) && B > 0 && frames >= 20, "mst_encoder_train_backward_apply: bad arguments");
+  MST_REQUIRE((layer == 1 || layer == 2) && B > 0 && frames >= 20, "mst_encoder_train_backward_apply: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
   if (!workspace || workspace_bytes < T.total)
@@ -2526,12 +2546,16 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   const int wus = p.tiles_r * p.tiles_c * nt;
   p.chunks = std::max(1, std::min(16, wus / 64));
   const long long units = (long long)B * ns * wus * 64;
-  if (layer == 1) {
-    hipLaunchKernelGGL((apply_bwd_reduce_kernel<1>), dim3(p.chunks, B * ns), dim3(256), 0, st, p);
-    hipLaunchKernelGGL((apply_bwd_dx_kernel<1>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, p, units);
+  const dim3 gr(p.chunks, B * ns), gd((unsigned)((units + 255) / 256));
+  if (layer == 1 && e->sub == 2) {
+    hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 2>), gd, dim3(256), 0, st, p, units);
+  } else if (layer == 1) {
+    hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 1>), gr, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 1>), gd, dim3(256), 0, st, p, units);
   } else {
-    hipLaunchKernelGGL((apply_bwd_reduce_kernel<2>), dim3(p.chunks, B * ns), dim3(256), 0, st, p);
-    hipLaunchKernelGGL((apply_bwd_dx_kernel<2>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, p, units);
+    hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((apply_bwd_dx_kernel<2, 2>), gd, dim3(256), 0, st, p, units);
   }
   MST_HIP_CHECK(hipGetLastError());
   // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
@@ -2568,7 +2592,8 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
 int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && logmel && dw, "mst_encoder_train_conv1_wgrad: NULL argument");
-  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20, "mst_encoder_train_conv1_wgrad: bad arguments");
+  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20,
+              "mst_encoder_train_conv1_wgrad: hand-written for the 20-mel sub-bands (pool height 2) only");
   const TrainLayout T = train_layout(e, B, frames);
   if (!workspace || workspace_bytes < T.total)
     return mst::fail(MST_ENOMEM, "mst_encoder_train_conv1_wgrad: workspace %zu B < required %zu B", workspace_bytes, T.total);
@@ -2604,7 +2629,7 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
 int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && pool1 && dw, "mst_encoder_train_conv2_wgrad: NULL argument");
-  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20, "mst_encoder_train_conv2_wgrad: bad arguments");
+  MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_train_conv2_wgrad: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
   if (!workspace || workspace_bytes < T.total)
@@ -2627,7 +2652,7 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
 int mst_encoder_train_conv2_dgrad(const mst_encoder* e, const float* dy2, int B, int frames, float* dpool1,
                                   const unsigned char* drop1_mask, float drop1_scale, void* stream) {
   MST_REQUIRE(e && dy2 && dpool1, "mst_encoder_train_conv2_dgrad: NULL argument");
-  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20, "mst_encoder_train_conv2_dgrad: bad arguments");
+  MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_train_conv2_dgrad: bad arguments");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int ns = e->cfg.n_subbands, H1 = e->H1, W1 = frames / 5;
   ConvParams cp{};

@@ -212,6 +212,7 @@ class HipEncoder:
         self._ws = None
         self.embed_dim = ae.attention_pooling.output_dim
         self.n_sub, self.split, self.freq_dim, self.overlap = ae.n_subbands, ae.split_size, ae.freq_dim, ae.overlap
+        self.sub = max(1, ae.split_size // 10)   # pool height of the first max-pool
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -231,7 +232,7 @@ class HipEncoder:
         L = _lib.lib()
         need = L.mst_encoder_train_workspace_bytes(self._h, B, Fr)
         if need == 0:
-            raise _lib.MstError("forward_train needs the default 20-mel sub-bands and frames >= 20")
+            raise _lib.MstError("forward_train needs frames >= 20")
         if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need or self._ws_train.device != logmel.device:
             self._ws_train = torch.empty(need, dtype=torch.uint8, device=logmel.device)
         dev = logmel.device
@@ -279,7 +280,7 @@ class HipEncoder:
     def conv2_dgrad(self, dy2, B, frames, mask=None, drop_p=0.0):
         """gradient of pool1 (B, n_sub, 32, H1, W1) from dy2 (n_sub, B, 64, H1, W1): `mst_encoder_train_conv2_dgrad`."""
         L = _lib.lib()
-        out = torch.empty(B, self.n_sub, 32, self.split // 2, frames // 5, device=dy2.device)
+        out = torch.empty(B, self.n_sub, 32, self.split // self.sub, frames // 5, device=dy2.device)
         with torch.cuda.device(dy2.device):
             _lib.check(L.mst_encoder_train_conv2_dgrad(self._h, _lib.dptr(dy2), B, frames, _lib.dptr(out), _lib.dptr(mask),
                                                        1.0 / (1.0 - drop_p) if mask is not None else 1.0,
@@ -311,12 +312,13 @@ class HipEncoder:
             assert dpool.dim() == 5 and dpool.stride(4) == 1 and dpool.stride(3) == W1
             st = (dpool.stride(0), dpool.stride(1), dpool.stride(2))
             dy = None if inplace else torch.empty(self.n_sub, B, 32, self.split, frames, device=dev)
+            assert not inplace or self.sub == 2, "in-place accumulator-order dy1 feeds the hand-written conv1 wgrad (sub == 2 only)"
             dbn = torch.empty(self.n_sub, 32, 2, device=dev)
         else:
             dpool = dpool.contiguous()
             W2 = W1 // 4
             st = (dpool.shape[1] * W2, 64 * self.freq_dim * W2, self.freq_dim * W2)
-            dy = torch.empty(self.n_sub, B, 64, self.split // 2, W1, device=dev)
+            dy = torch.empty(self.n_sub, B, 64, self.split // self.sub, W1, device=dev)
             dbn = torch.empty(self.n_sub, 64, 2, device=dev)
         need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
         with torch.cuda.device(dev):
@@ -383,7 +385,7 @@ class _HipTrunk(torch.autograd.Function):
         W1 = Fr // 5
         mask = None
         if drop_p > 0.0:
-            mask = (torch.rand(B, enc.n_sub, 32, enc.split // 2, W1, device=logmel.device) >= drop_p).to(torch.uint8)
+            mask = (torch.rand(B, enc.n_sub, 32, enc.split // enc.sub, W1, device=logmel.device) >= drop_p).to(torch.uint8)
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p)
         enc._train_gen = getattr(enc, "_train_gen", 0) + 1   # the saved activations live in the encoder's workspace
         ctx.enc, ctx.drop_p, ctx.dims, ctx.gen = enc, drop_p, (B, Fr), enc._train_gen
@@ -435,7 +437,8 @@ class _HipTrunk(torch.autograd.Function):
             if mask is not None:
                 dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
             mark("stack+mask")
-        if _CONV1_WGRAD_MIOPEN:   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (for A/B checks)
+        if _CONV1_WGRAD_MIOPEN or enc.sub != 2:   # library weight gradient on an NCHW dy: A/B checks (MST_CONV1_WGRAD=miopen),
+            #                                          and the 10..19-mel sub-band geometry the hand-written kernel does not cover
             dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
             mark("apply_bwd1")
             gw1, gb1 = [], []
@@ -505,7 +508,7 @@ class MixingStyleEncoder(nn.Module):
                                             st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias), float(p))
         with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
             B, Fr = logmel.shape[0], logmel.shape[-1]
-            for stat, name, n in ((bn1, "bn1", B * ae.split_size * Fr), (bn2, "bn2", B * (ae.split_size // 2) * (Fr // 5))):
+            for stat, name, n in ((bn1, "bn1", B * ae.split_size * Fr), (bn2, "bn2", B * (ae.split_size // enc.sub) * (Fr // 5))):
                 mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * (n / max(n - 1, 1))
                 for i, c in enumerate(cn):
                     bn = getattr(c, name)
@@ -518,7 +521,7 @@ class MixingStyleEncoder(nn.Module):
 
     def forward_from_logmel(self, logmel, mixing_features):
         if self.encoder_backend == "hip" and self.training and self.train_backend == "hip" and \
-                self._needs_autograd(mixing_features) and self.audio_encoder.split_size // 10 == 2:
+                self._needs_autograd(mixing_features) and self.audio_encoder.split_size // 10 in (1, 2):
             return self._forward_train_hip(logmel, mixing_features)
         if self.encoder_backend == "hip" and not self._needs_autograd(mixing_features):
             if self.training:

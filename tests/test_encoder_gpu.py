@@ -281,50 +281,65 @@ def test_train_mode_backward_of_pool_relu_film_batchnorm():
     close(dfilm.cpu(), film.grad, 2e-4)
 
 
-def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules():
-    """`train_backend="hip"` (trunk forward + pool/ReLU/FiLM/BN backward in libmst.so, conv gradients via MIOpen) against
-    the same model on the all-PyTorch training path: loss, every parameter gradient, running statistics.  Dropout off
-    (p = 0) for the comparison; with p = 0.3 the native forward must agree with the masks it reports."""
+@pytest.mark.parametrize("cfgname", ["default", "baseline_sh"])
+def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgname):
+    """`train_backend="hip"` (conv trunk forward + backward in libmst.so) against PyTorch autograd of the same modules
+    evaluated in FLOAT64: loss, every parameter gradient, running statistics.  Almost all gradients agree to ~2e-6.  A max-pool
+    arg-max is not differentiable at ties: where two values of a window agree to the last fp32 bits, an fp32 implementation
+    may route the gradient to the other element than float64 does, which moves the gradients of that sub-band's conv / BN
+    parameters by 1e-3 .. 4e-2.  This hits the hand-written kernels and PyTorch's own fp32 path alike (on the reference's
+    train_baseline.sh shapes PyTorch fp32 is the one that is 3.7e-2 off in one sub-band, the HIP trunk is at 2e-6), so the
+    check is: every tensor within 5e-2, at least 95 % of them within 1e-4, and no more outliers than PyTorch fp32 has + 3.
+    Dropout off (p = 0) for the comparison; with p = 0.3 the native forward must agree with the mask it is given."""
     import copy
-    cfg = cases.CFG_DEFAULT
+    cfg = cases.CFG_DEFAULT if cfgname == "default" else cases.CFG_BASELINE_SH   # the reference's scripts/train_baseline.sh
     model, sd = build_model(cfg)
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
-    ref = copy.deepcopy(model)
-    model.train(), ref.train()
-    model.train_backend, ref.train_backend = "hip", "torch"
+    ref32 = copy.deepcopy(model)
+    ref64 = copy.deepcopy(model).double()
+    for m_ in (model, ref32, ref64):
+        m_.train()
+    model.train_backend, ref32.train_backend, ref64.train_backend = "hip", "torch", "torch"
     B, T = 4, 44100
     x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0).cuda()
     stems = omel.tensor_to_stems_dict(x)
     g = torch.Generator().manual_seed(8)
     feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
-    R = torch.randn(B, 768, generator=g).cuda()
-    la = (model(stems, feats) * R).sum()
-    lb = (ref(stems, feats) * R).sum()
-    la.backward(), lb.backward()
-    close(la.item(), lb.item(), 1e-4)
-    worst, errs = 0.0, {}
+    R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(stems)
+    la = (model.forward_from_logmel(lm, feats) * R).sum()
+    lb = (ref32.forward_from_logmel(lm, feats) * R).sum()
+    lc = (ref64.forward_from_logmel(lm.double(), feats.double()) * R.double()).sum()
+    la.backward(), lb.backward(), lc.backward()
+    close(la.item(), lc.item(), 1e-5)
+    worst_hip = worst_t32 = 0.0
+    errs = []
     grads = dict(model.named_parameters())
-    for (n, pa), (_, pb) in zip(model.named_parameters(), ref.named_parameters()):
+    for (n, pa), (_, pb), (_, pc) in zip(model.named_parameters(), ref32.named_parameters(), ref64.named_parameters()):
         assert pa.grad is not None, n
+        den = pc.grad.abs().max().item()
         if "subnet_cnns" in n and n.endswith(("conv1.bias", "conv2.bias")):
-            # a bias in front of a batch-statistics BatchNorm has gradient exactly 0 (the mean is removed): both paths
-            # return rounding noise -- it must be negligible next to the layer's weight gradient
+            # a bias in front of a batch-statistics BatchNorm has gradient exactly 0 (the mean is removed)
             wmax = grads[n[:-4] + "weight"].grad.abs().max().item()
-            assert pa.grad.abs().max().item() < 1e-3 * wmax and pb.grad.abs().max().item() < 1e-3 * wmax, n
+            assert pa.grad.abs().max().item() < 1e-3 * wmax, n
             continue
-        d = (pa.grad - pb.grad).abs().max().item() / max(pb.grad.abs().max().item(), 1e-12)
-        worst = max(worst, d)
-        errs[n] = d
-    bad = {n: f"{d:.1e}" for n, d in errs.items() if d > 1e-3}
-    print(f"hip-trunk training vs torch autograd: worst relative parameter-gradient error {worst:.2e}; >1e-3: {bad}")
-    # conv weight gradients are sums of B*H*W products with heavy cancellation: the fp32 noise of dy (1e-4 of its max,
-    # checked in the test above) shows up amplified there
-    assert all(d < (1e-2 if "conv" in n else 2e-3) for n, d in errs.items()), bad
-    for (n, ba), (_, bb) in zip(model.named_buffers(), ref.named_buffers()):
+        if den < 1e-9 * max(1.0, pc.abs().max().item()):   # e.g. attention.2.bias: softmax is shift-invariant
+            continue
+        d_hip = (pa.grad.double() - pc.grad).abs().max().item() / den
+        d_t32 = (pb.grad.double() - pc.grad).abs().max().item() / den
+        worst_hip, worst_t32 = max(worst_hip, d_hip), max(worst_t32, d_t32)
+        errs.append((n, d_hip, d_t32))
+    out_hip = [(n, f"{a:.1e}") for n, a, _ in errs if a >= 1e-4]
+    out_t32 = [(n, f"{b:.1e}") for n, _, b in errs if b >= 1e-4]
+    print(f"{cfgname}: parameter-gradient error vs float64 autograd over {len(errs)} tensors: hip trunk worst {worst_hip:.2e}, "
+          f"outliers {out_hip}; PyTorch fp32 worst {worst_t32:.2e}, {len(out_t32)} outliers")
+    assert worst_hip < 5e-2 and len(out_hip) <= 0.05 * len(errs) and len(out_hip) <= len(out_t32) + 3, out_hip
+    for (n, ba), (_, bc) in zip(model.named_buffers(), ref64.named_buffers()):
         if "running" in n:
-            close(ba.cpu(), bb.cpu(), 2e-4)
+            close(ba.cpu(), bc.cpu(), 1e-4)
     # two forward passes alive at once are refused loudly (one activation workspace per model)
     o1 = model(stems, feats).sum()
     o2 = model(stems, feats).sum()
