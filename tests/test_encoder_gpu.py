@@ -284,11 +284,11 @@ def test_train_mode_backward_of_pool_relu_film_batchnorm():
 @pytest.mark.parametrize("cfgname", ["default", "baseline_sh"])
 def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgname):
     """`train_backend="hip"` (conv trunk forward + backward in libmst.so) against PyTorch autograd of the same modules
-    evaluated in FLOAT64: loss, every parameter gradient, running statistics.  Almost all gradients agree to ~2e-6.  A max-pool
-    arg-max is not differentiable at ties: where two values of a window agree to the last fp32 bits, an fp32 implementation
-    may route the gradient to the other element than float64 does, which moves the gradients of that sub-band's conv / BN
-    parameters by 1e-3 .. 4e-2.  This hits the hand-written kernels and PyTorch's own fp32 path alike (on the reference's
-    train_baseline.sh shapes PyTorch fp32 is the one that is 3.7e-2 off in one sub-band, the HIP trunk is at 2e-6), so the
+    evaluated in FLOAT64: loss, every parameter gradient, running statistics.  Almost all gradients agree to ~2e-6.  Isolated
+    larger deviations are fp32 effects that hit ANY fp32 implementation -- sums over 10^5 positions with heavy cancellation
+    (conv1.weight of the lowest sub-band: x ~ -23, the log-mel silence floor, against sum(dy) = 0), near-tie max-pool arg-max
+    decisions, fp32 BatchNorm reductions -- and PyTorch's own fp32 path shows more of them (on the reference's
+    train_baseline.sh shapes it is 3.7e-2 off in one sub-band where the HIP trunk is at 2e-6), so the
     check is: every tensor within 5e-2, at least 95 % of them within 1e-4, and no more outliers than PyTorch fp32 has + 3.
     Dropout off (p = 0) for the comparison; with p = 0.3 the native forward must agree with the mask it is given."""
     import copy
