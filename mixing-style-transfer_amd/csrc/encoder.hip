@@ -1552,15 +1552,19 @@ struct WgradParams {
 };
 
 // NW waves per workgroup (4: two independent workgroups per CU, so that one's loads / barrier overlap the other's MFMAs)
-template <int NW, int DBG>   // DBG: timing experiments (MST_WGRAD_DBG): 1 no dy/patch refetch, 2 no staging/barrier, 3 both
+// SUB: pool height of the layer (tile = SUB rows x 40 / 80 columns, patch 8 x (SUB + 6) x 46 / 86)
+template <int SUB, int NW, int DBG>   // DBG: timing experiments (MST_WGRAD_DBG): 1 no dy/patch refetch, 2 no staging/barrier, 3 both
 __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams p) {
-  using C = CC<1, 2>;
-  constexpr int PR = C::PR, PC = C::PC, CHS = PR * PC, PATCH = 8 * CHS;   // 8 x 8 x 46
+  using C = CC<1, SUB>;
+  constexpr int PR = C::PR, PC = C::PC, CHS = PR * PC, PATCH = 8 * CHS;
+  constexpr int NCV = (PC + 63) / 64;  // 64-lane loads per patch row
+  constexpr int GSTEP = 5 * C::WPG;    // column distance between the lane groups' positions
   constexpr int NTN = 25;             // N-tiles of 16 over the 392 (ci, tap) columns
   constexpr int KF = (NTN - 1) / NW;        // full N-tiles per wave: nt = wave + NW*k, k < KF (24 of the 25)
   constexpr bool SHARED = true;             // N-tile 24 (half empty): its 20 k-steps are dealt over the waves
   constexpr int KN = KF + 1;
-  constexpr int RPW = 64 / NW;        // patch rows a wave loads per tile
+  constexpr int RPW = (8 * PR * NCV + NW - 1) / NW;   // row pieces (64-lane loads) a wave issues per tile
+  static_assert(RPW <= 32, "mask bits");
   __shared__ float patch[2][PATCH];
   __shared__ __attribute__((aligned(16))) float dybuf[2][2 * 64 * 20];   // the tile's dy, fetched ONCE per workgroup
   constexpr int NDY = (2 * 64 * 5 + NW * 64 - 1) / (NW * 64);               // float4 loads per thread
@@ -1580,14 +1584,14 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     const int nidx = (wave + NW * k) * 16 + j;
     const bool ok = true;   // N-tiles 0..23 are full
     const int ci = ok ? nidx / 49 : 0, tap = ok ? nidx % 49 : 0;
-    nbase[k] = ci * CHS + (tap / 7) * PC + tap % 7 + 10 * g;
+    nbase[k] = ci * CHS + (tap / 7) * PC + tap % 7 + GSTEP * g;
     nmask[k] = ok ? 1.f : 0.f;
   }
   // shared N-tile 24: waves 0..3 take 3 k-steps, waves 4..7 two (NW = 8); with NW = 4 every wave takes 5
   const int sh_cnt = NW == 8 ? (wave < 4 ? 3 : 2) : 5;
   const int sh_e0 = NW == 8 ? (wave < 4 ? 3 * wave : 12 + 2 * (wave - 4)) : 5 * wave;
   const int sh_nidx = (NTN - 1) * 16 + j;
-  const int sh_base = (sh_nidx < 392 ? (sh_nidx / 49) * CHS + ((sh_nidx % 49) / 7) * PC + (sh_nidx % 49) % 7 : 0) + 10 * g;
+  const int sh_base = (sh_nidx < 392 ? (sh_nidx / 49) * CHS + ((sh_nidx % 49) / 7) * PC + (sh_nidx % 49) % 7 : 0) + GSTEP * g;
   const float sh_mask = sh_nidx < 392 ? 1.f : 0.f;
 
   struct TileId {
@@ -1617,15 +1621,12 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
   // current tile: all waves of the workgroup run in lockstep (one barrier per tile), so a block of loads at the top
   // of the tile would leave every matrix pipe idle while it issues
   const float* pf_src = p.x;
-  int pf_row0 = 0, pf_cl = 0;
-  bool pf_colok = false;
+  int pf_row0 = 0, pf_col0 = 0;
   const f32x4* dy_src = reinterpret_cast<const f32x4*>(p.dy);
   auto prefetch_setup = [&](const TileId& t) __attribute__((always_inline)) {
     pf_src = p.x + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
     pf_row0 = C::TROWS * t.tr - 3;
-    const int cin = C::TCOLS * t.tc - 3 + lane;
-    pf_colok = lane < PC && cin >= 0 && cin < p.in_cols;
-    pf_cl = min(max(cin, 0), p.in_cols - 1);
+    pf_col0 = C::TCOLS * t.tc - 3;
     const size_t u = ((((size_t)t.clip * p.nsub + t.band) * p.tiles_r + t.tr) * p.tiles_c + t.tc) * 2;
     dy_src = reinterpret_cast<const f32x4*>(p.dy + u * 64 * 20);
   };
@@ -1633,12 +1634,14 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     if ((DBG & 8) && i < RPW) return;
     if ((DBG & 16) && i >= RPW) return;
     if (i < RPW) {
-      const int row = wave * RPW + i, cc = row / PR, r = row % PR;
+      const int idx = wave * RPW + i, row = min(idx / NCV, 8 * PR - 1), cv = idx % NCV;
+      const int cc = row / PR, r = row % PR, col = lane + 64 * cv;
       const int rin = pf_row0 + r, rc = min(max(rin, 0), p.in_rows - 1);
+      const int cin = pf_col0 + col, cl = min(max(cin, 0), p.in_cols - 1);
       // the out-of-image mask is applied when the row is staged: touching the value here would make the wave wait
       // for the load on the spot
-      pf[i] = (pf_src + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[pf_cl];
-      if (pf_colok && rin == rc) pmask |= 1u << i;
+      pf[i] = (pf_src + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[cl];
+      if (idx < 8 * PR * NCV && col < PC && cin == cl && rin == rc) pmask |= 1u << i;
     } else if (i < RPW + NDY) {
       dq[i - RPW] = dy_src[min(tid + (i - RPW) * NW * 64, 2 * 64 * 5 - 1)];
     }
@@ -1650,12 +1653,12 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     for (int i = 0; i < RPW + NDY; ++i) prefetch_piece(i, pf, dq, pmask);
   };
   auto stage = [&](int buf, const float (&pf)[RPW], unsigned pmask) __attribute__((always_inline)) {
-    if (lane < PC) {
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) patch[buf][(wave * RPW + i) * PC + lane] = ((pmask >> i) & 1u) ? pf[i] : 0.f;
+    for (int i = 0; i < RPW; ++i) {
+      const int idx = wave * RPW + i, row = idx / NCV, col = lane + 64 * (idx % NCV);
+      if (idx < 8 * PR * NCV && col < PC) patch[buf][row * PC + col] = ((pmask >> i) & 1u) ? pf[i] : 0.f;
     }
   };
-
   f32x4 acc[2][KN];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
@@ -1681,8 +1684,6 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
 
   if (s_begin >= s_end) return;
   int cur_band = -1;
-  // A operand of a tile: its dy in accumulator order, both channel tiles; fetched one tile ahead into the OTHER of two
-  // explicit register sets (the loop is unrolled by two so that the compiler cannot merge them and sink the loads)
   auto stage_dy = [&](int buf, const f32x4 (&dq)[NDY]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < NDY; ++i)
@@ -1741,7 +1742,8 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
         const float b = bq[k & 1][e];
         acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
         acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
-        if (!(DBG & 1) && (e % 5) == 2) {   // one prefetch instruction per 10 MFMAs
+        // one prefetch instruction per 10 MFMAs (12 slots), or per 5 when the tile needs more than 12 pieces
+        if (!(DBG & 1) && (RPW + NDY > 12 ? ((e % 5) == 1 || (e % 5) == 3) : (e % 5) == 2)) {
           prefetch_piece(piece, pfn, dqn, pmn);
           ++piece;
         }
@@ -2592,8 +2594,7 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
 int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && logmel && dw, "mst_encoder_train_conv1_wgrad: NULL argument");
-  MST_REQUIRE(e->sub == 2 && B > 0 && frames >= 20,
-              "mst_encoder_train_conv1_wgrad: hand-written for the 20-mel sub-bands (pool height 2) only");
+  MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_train_conv1_wgrad: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   if (!workspace || workspace_bytes < T.total)
     return mst::fail(MST_ENOMEM, "mst_encoder_train_conv1_wgrad: workspace %zu B < required %zu B", workspace_bytes, T.total);
@@ -2606,22 +2607,9 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
                  (long long)8 * e->cfg.n_mels * frames, 0};
   const long long total = (long long)ns * B * T.tr1 * T.tc1;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv1_wgrad: too many tiles");
-  const int dbg = getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0;
-  const int nw = getenv("MST_WGRAD_WAVES") ? atoi(getenv("MST_WGRAD_WAVES")) : 8;
-  if (nw == 8) {
-    const int g8 = (int)std::min<long long>(e->num_cus, total);
-    if (dbg == 3) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 3>), dim3(g8), dim3(512), 0, st, wp);
-    else if (dbg == 1) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 1>), dim3(g8), dim3(512), 0, st, wp);
-    else if (dbg == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 2>), dim3(g8), dim3(512), 0, st, wp);
-    else if (dbg == 4) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 4>), dim3(g8), dim3(512), 0, st, wp);
-    else if (dbg == 8) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 8>), dim3(g8), dim3(512), 0, st, wp);
-    else if (dbg == 16) hipLaunchKernelGGL((conv1_wgrad_kernel<8, 16>), dim3(g8), dim3(512), 0, st, wp);
-    else hipLaunchKernelGGL((conv1_wgrad_kernel<8, 0>), dim3(g8), dim3(512), 0, st, wp);
-  } else {
-    const int g4 = (int)std::min<long long>(2 * e->num_cus, total);
-    if (dbg == 3) hipLaunchKernelGGL((conv1_wgrad_kernel<4, 3>), dim3(g4), dim3(256), 0, st, wp);
-    else hipLaunchKernelGGL((conv1_wgrad_kernel<4, 0>), dim3(g4), dim3(256), 0, st, wp);
-  }
+  const int g8 = (int)std::min<long long>(e->num_cus, total);
+  if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
+  else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }

@@ -312,7 +312,6 @@ class HipEncoder:
             assert dpool.dim() == 5 and dpool.stride(4) == 1 and dpool.stride(3) == W1
             st = (dpool.stride(0), dpool.stride(1), dpool.stride(2))
             dy = None if inplace else torch.empty(self.n_sub, B, 32, self.split, frames, device=dev)
-            assert not inplace or self.sub == 2, "in-place accumulator-order dy1 feeds the hand-written conv1 wgrad (sub == 2 only)"
             dbn = torch.empty(self.n_sub, 32, 2, device=dev)
         else:
             dpool = dpool.contiguous()
@@ -437,8 +436,7 @@ class _HipTrunk(torch.autograd.Function):
             if mask is not None:
                 dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
             mark("stack+mask")
-        if _CONV1_WGRAD_MIOPEN or enc.sub != 2:   # library weight gradient on an NCHW dy: A/B checks (MST_CONV1_WGRAD=miopen),
-            #                                          and the 10..19-mel sub-band geometry the hand-written kernel does not cover
+        if _CONV1_WGRAD_MIOPEN:   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (for A/B checks)
             dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
             mark("apply_bwd1")
             gw1, gb1 = [], []
