@@ -357,6 +357,29 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgnam
     assert torch.equal(t1["pool1"], torch.where(mask.bool(), t0["pool1"] * (1.0 / 0.7), torch.zeros_like(t0["pool1"])))
 
 
+@pytest.mark.parametrize("cfgname", ["default", "baseline_sh"])
+def test_conv2_input_gradient_with_dropout_mask(cfgname):
+    """`mst_encoder_train_conv2_dgrad` (chunked fp32-MFMA conv on dy2 with transposed / flipped weights, Dropout keep-mask
+    fused into the store) against the float64 input gradient of F.conv2d times the same mask."""
+    cfg = cases.CFG_DEFAULT if cfgname == "default" else cases.CFG_BASELINE_SH
+    model, sd = build_model(cfg)
+    from mst_amd.model import HipEncoder
+    enc = HipEncoder(model, "fp32")
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    B, frames = 3, 431
+    H1, W1 = cfg["split_size"] // enc.sub, frames // 5
+    g = torch.Generator().manual_seed(12)
+    dy2 = torch.randn(ns, B, 64, H1, W1, generator=g)
+    mask = (torch.rand(B, ns, 32, H1, W1, generator=g) >= 0.3).to(torch.uint8)
+    got = enc.conv2_dgrad(dy2.cuda(), B, frames, mask.cuda(), 0.3).cpu()
+    got_nomask = enc.conv2_dgrad(dy2.cuda(), B, frames).cpu()
+    for i in (0, ns // 2, ns - 1):
+        w = sd[f"audio_encoder.subnet_cnns.{i}.conv2.weight"].double()
+        ref = torch.nn.grad.conv2d_input((B, 32, H1, W1), w, dy2[i].double(), padding=3)
+        close(got_nomask[:, i], ref, 1e-5)
+        close(got[:, i], ref * mask[:, i].double() / 0.7, 1e-5)
+
+
 def test_song_a_real_music_end_to_end():
     """BASELINE configs[0] on the GPU: real music through stage A + HIP encoder vs the reference goldens (bs=2)."""
     from test_melfeat_gpu import check_feats, check_logmel
