@@ -143,6 +143,16 @@ struct CC<3, SUB> {  // conv2 INPUT gradient: Conv2d(64 -> 32, 7x7, pad 3) of d(
   static constexpr int RL = 64;
 };
 
+template <int SUB>
+struct CC<4, SUB> {  // conv2 (32 -> 64) on conv1's 2 x 40 tile geometry: the training forward's 2-row strip (output rows
+                     // 8, 9 of 10 exist only for the batch statistics; an 8 x 8 tile there would be 75 % padding)
+  static constexpr int CIN = 32, COUT = 64, NCH = 8, MT = 5, NT = 4;
+  static constexpr int WIN = 10, WPG = 2;
+  static constexpr int TROWS = 2, TCOLS = 40;
+  static constexpr int PR = TROWS + 6, PC = TCOLS + 6;
+  static constexpr int RL = 64;
+};
+
 struct ConvParams {
   const float* in;
   const float* wfrag;  // [nsub][NCH][WBP]   B fragments: [tap][nt][lane], zero padded to the chunk pitch
@@ -168,6 +178,9 @@ struct ConvParams {
   // MODE 2 (conv2 input gradient): raw output to out[clip][band][COUT][raw_rows][raw_cols], times the Dropout keep-mask
   const unsigned char* mask;
   float mask_scale;
+  // accumulator-order layout of yraw (tile rows / columns of the 8 x 8 or SUB x 40 tiling it is indexed by) and the
+  // first output row of this launch (MODE 3: the strip kernel scatters its 2-row tiles into the 8 x 8 layout)
+  int acc_tr, acc_tc, row_off;
 };
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
@@ -205,8 +218,9 @@ template <int LAYER, int SUB, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) {
   using C = CC<LAYER, SUB>;
   using GEO = ConvGeom<LAYER, SUB>;
-  static_assert(MODE == 0 || (MODE == 1 && LAYER != 3) || (MODE == 2 && LAYER == 3), "raw modes: forward layers, conv2 dgrad");
-  constexpr bool GEO1 = LAYER == 1 || LAYER == 3;   // 2 x 40 tiles, pooling-window accumulator order
+  static_assert(MODE == 0 || (MODE == 1 && LAYER <= 2) || (MODE == 2 && LAYER == 3) || (MODE == 3 && LAYER == 4),
+                "raw modes: forward layers, conv2 dgrad, conv2 strip");
+  constexpr bool GEO1 = LAYER == 1 || LAYER >= 3;   // 2 x 40 tiles, pooling-window accumulator order
   constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
   constexpr int WBP = GEO::WBP, PATCH = GEO::PATCH, NWF = GEO::NWF, NPF = GEO::NPF, NCV = GEO::NCV;
   constexpr int NPIECE = NPF + NWF, PPT = (NPIECE + 48) / 49;  // prefetch pieces, pieces issued per tap
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
   auto prefetch_setup = [&](int q, const Tile& t) __attribute__((always_inline)) {
     const int chunk = q % NCH;
     nwsrc = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)t.band * NCH + chunk) * WBP);
-    nrow0 = (GEO1 ? C::TROWS * t.tr : 8 * t.tr) - 3;
+    nrow0 = (GEO1 ? C::TROWS * t.tr : 8 * t.tr) + (MODE == 3 ? p.row_off : 0) - 3;
     ncol0 = C::TCOLS * t.tc - 3;
     nvalid = t.valid;
     nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff + (size_t)(4 * chunk) * p.in_cstride;
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
         if (st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
         st_band = cur.band;
       }
-      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.tiles_r + cur.tr) * p.tiles_c + cur.tc) *
+      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) *
                                (size_t)(NT * 64 * 4 * MT);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -405,6 +419,32 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
             if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
           dst[t] = v;
+        }
+      }
+    }
+    if (MODE == 3 && chunk == NCH - 1 && cur.valid) {
+      // conv2 strip (training forward): raw output + bias scattered into the 8 x 8-tile accumulator layout the
+      // downstream kernels index, batch-statistics sums over the valid positions
+      const int j = lane & 15, g = lane >> 4;
+      if (cur.band != st_band) {
+        if (st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
+        st_band = cur.band;
+      }
+      float* yplane = p.yraw + ((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr * p.acc_tc * (size_t)(NT * 64 * 16);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float b = p.bias[cur.band * C::COUT + n * 16 + j];
+#pragma unroll
+        for (int e = 0; e < 4 * MT; ++e) {
+          const int wv = e / C::WIN, pos = e % C::WIN;
+          const int row = p.row_off + C::TROWS * cur.tr + pos / 5, col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
+          if (row < p.raw_rows && col < p.raw_cols) {
+            const float v = acc[e >> 2][n][e & 3] + b;
+            st[n][0] += (double)v, st[n][1] += (double)v * (double)v;
+            const int tr8 = row >> 3, rr = row & 7, tc8 = col >> 3, cc8 = col & 7;
+            const int lane8 = 16 * (((rr >> 2) << 1) | (cc8 >> 2)) + j, e8 = 4 * (rr & 3) + (cc8 & 3);
+            yplane[((((size_t)tr8 * p.acc_tc + tc8) * NT + n) * 64 + lane8) * 16 + e8] = v;
+          }
         }
       }
     }
@@ -465,7 +505,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
       }
     }
   }
-  if (MODE == 1 && st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
+  if ((MODE == 1 || MODE == 3) && st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -608,7 +648,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
     if constexpr (MODE == 1) {
       // training forward: raw output + bias in accumulator order, batch-statistics sums over the valid columns
       const int j = lane & 15, g = lane >> 4;
-      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.tiles_r + cur.tr) * p.tiles_c + cur.tc) *
+      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) *
                                (size_t)(NT * 64 * 4 * MT);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
@@ -1298,7 +1338,8 @@ __global__ void bn_fold_kernel(const FoldParams p) {   // grid (nsub, B), block 
 }
 
 struct ApplyParams {
-  const float* yraw;
+  float* yraw;             // layer 2: the slots of rows past raw_rows are zeroed on the way (the strip kernel does not write them)
+  int raw_rows;
   const float2* aff;
   float* out;
   const unsigned char* mask;   // optional Dropout keep-mask over the pooled output (layer 1), same layout as `out`
@@ -1322,11 +1363,17 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
   const int band = (int)(tile % p.nsub), clip = (int)(tile / p.nsub);
   const int j = lane & 15, g = lane >> 4, ch = n * 16 + j;
   const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
-  const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (size_t)u * NV);
+  f32x4* src = reinterpret_cast<f32x4*>(p.yraw + (size_t)u * NV);
   float v[NV];
 #pragma unroll
   for (int t = 0; t < C::MT; ++t) {
-    const f32x4 q = src[t];
+    f32x4 q = src[t];
+    if constexpr (LAYER == 2) {
+      if (8 * tr + 4 * (g >> 1) + t >= p.raw_rows) {   // no such output row: keep the slot finite for the backward pass
+        q = f32x4{0.f, 0.f, 0.f, 0.f};
+        src[t] = q;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
   }
@@ -2418,6 +2465,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.tiles_r = T.tr1, cp.tiles_c = T.tc1;
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     cp.yraw = y1, cp.stats = stats1, cp.bias = e->c1b, cp.raw_rows = e->cfg.split_size, cp.raw_cols = frames;
+    cp.acc_tr = T.tr1, cp.acc_tc = T.tc1;
     const int g = std::min(grid, ns * cp.sets_per_band);
     if (e->sub == 2) {
       using C = CC<1, 2>;
@@ -2447,7 +2495,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, (double)B * e->cfg.split_size * frames, e->cfg.bn_eps,
                   ns, 32, 0, 32};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
-    ApplyParams ap{y1, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
+    ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
                    B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64};
     if (e->sub == 2) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     else hipLaunchKernelGGL((apply_kernel<1, 1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
@@ -2461,25 +2509,51 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.in_bandoff = 32 * e->H1 * L.W1;
     cp.in_clipstride = (long long)ns * 32 * e->H1 * L.W1;
     cp.out_rows = e->FD, cp.out_cols = L.W2;
-    cp.tiles_r = T.tr2, cp.tiles_c = T.tc2;
+    // the last tile row holds at most 2 real output rows (rows 8, 9 of 10 at the default geometry): those go through
+    // the 2 x 40-tile strip kernel instead of 8 x 8 tiles that would be 75 % padding
+    const int rows_last = e->H1 - 8 * (T.tr2 - 1);
+    const bool strip = T.tr2 >= 2 && rows_last <= 2 && !getenv("MST_CONV2_NO_STRIP");
+    cp.tiles_r = strip ? T.tr2 - 1 : T.tr2, cp.tiles_c = T.tc2;
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     cp.yraw = y2, cp.stats = stats2, cp.bias = e->c2b, cp.raw_rows = e->H1, cp.raw_cols = L.W1;
-    const int g = std::min(grid, ns * cp.sets_per_band);
-    using GEO = ConvGeom<2, 2>;
-    const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-      err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<2, 2, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 (train) attribute failed: %s", hipGetErrorString(err));
-      attr_set = true;
+    cp.acc_tr = T.tr2, cp.acc_tc = T.tc2;
+    {
+      const int g = std::min(grid, ns * cp.sets_per_band);
+      using GEO = ConvGeom<2, 2>;
+      const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<2, 2, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 (train) attribute failed: %s", hipGetErrorString(err));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
+      MST_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
-    MST_HIP_CHECK(hipGetLastError());
+    if (strip) {
+      ConvParams sp = cp;
+      sp.row_off = 8 * (T.tr2 - 1);
+      sp.tiles_r = (rows_last + 1) / 2, sp.tiles_c = (L.W1 + 39) / 40;
+      sp.sets_per_band = (B * sp.tiles_r * sp.tiles_c + kConvWaves - 1) / kConvWaves;
+      const int g = std::min(grid, ns * sp.sets_per_band);
+      using GEO = ConvGeom<4, 2>;
+      static_assert(GEO::WBP == ConvGeom<2, 2>::WBP, "the strip kernel streams conv2's forward weight fragments");
+      const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
+      static bool attr_set = false;
+      if (!attr_set) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<4, 2, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 strip attribute failed: %s", hipGetErrorString(err));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((conv_kernel<4, 2, 3>), dim3(g), dim3(kConvThreads), lds, st, sp);
+      MST_HIP_CHECK(hipGetLastError());
+    }
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn2);
     FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
-    ApplyParams ap{y2, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
+    ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
     hipLaunchKernelGGL((apply_kernel<2, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
