@@ -520,7 +520,8 @@ class MixingStyleEncoder(nn.Module):
     def forward_from_logmel(self, logmel, mixing_features):
         if self.encoder_backend == "hip" and self.training and self.train_backend == "hip" and \
                 self._needs_autograd(mixing_features) and self.audio_encoder.split_size // 10 in (1, 2) and \
-                logmel.is_cuda and logmel.shape[-1] >= 20:
+                logmel.is_cuda and logmel.shape[-1] >= 20 and logmel.dtype == torch.float32 and \
+                self.film_encoder.film_head.weight.dtype == torch.float32:
             return self._forward_train_hip(logmel, mixing_features)
         if self.encoder_backend == "hip" and not self._needs_autograd(mixing_features):
             if self.training:
