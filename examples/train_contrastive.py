@@ -45,6 +45,8 @@ def main(argv=None):
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--train-backend", choices=["hip", "torch"], default="hip",
+                    help="hip: conv trunk forward + backward in libmst.so (default); torch: PyTorch-ROCm autograd")
     a = ap.parse_args(argv)
     sr = 44100
     if a.synthetic:
@@ -56,6 +58,7 @@ def main(argv=None):
     dl = DataLoader(ds, batch_size=a.batch_size, shuffle=True, drop_last=True, num_workers=a.workers,
                     collate_fn=ingest.pcm_collate_fn, pin_memory=True)
     model = MixingStyleEncoder(sr, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).to(dev).train()
+    model.train_backend = a.train_backend
     fe = MixingFeatureExtractor(sr, 1024, 256, 128)
     crit = InfoNCELoss(0.1)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr)
