@@ -3,10 +3,13 @@ baseline_collate_fn -- same signatures, return tuples and exceptions (SURVEY.md 
 
 Differences forced by the device path:
   * `compute_features`: the reference computes the 64-d features inside the (fork'd) DataLoader worker on the CPU
-    (src/data.py:231-265).  A HIP context cannot be used after fork, so with the default `compute_features="auto"`
-    the worker returns `None` placeholders when it has no GPU context and the features are produced per batch on
-    the device (`MixingFeatureExtractor.features_and_logmel`).  `compute_features=True` computes them in
-    `__getitem__` on the GPU (main process / spawn workers only).
+    (src/data.py:231-265).  A HIP context cannot be used after fork, so with the default `compute_features="deferred"`
+    every features slot holds a PLACEHOLDER row -- a real `(feature_dim,)` fp32 tensor filled with
+    `mixing_utils.FEATURES_DEFERRED` -- which survives `torch.stack`, `torch.isnan(...)`, `.to(device)`
+    (src/train.py:237,243) and `features_list[0].shape[0]` (src/train.py:523) unchanged, and
+    `MixingStyleEncoder.forward(stems_dict, mixing_features)` fills such rows on the device from the same stage-A
+    launch that produces its log-mel (one pass over the waveform, no host sync).  `compute_features=True` computes
+    the real features in `__getitem__` on the GPU (main process / spawn workers only).
   * stem decoding: the reference reads `{stem}.mp3` with torchaudio.load (not installed here).  Decoding stays a
     host concern (SURVEY 8 f2): `stem_loader` is a pluggable callable `path -> (tensor (C, L), sample_rate)`;
     the default tries torchaudio, then a PCM `.wav` reader for pre-decoded stems.
@@ -21,7 +24,7 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
-from .mixing_utils import STEMS, MixingFeatureExtractor
+from .mixing_utils import STEMS, MixingFeatureExtractor, deferred_features
 
 _SEPARATOR_BACKEND = None
 
@@ -68,21 +71,44 @@ def _load_wav(path):
     return torch.from_numpy(a.reshape(-1, ch).T.copy()), sr
 
 
+def _is_riff(path):
+    try:
+        with open(path, "rb") as f:
+            h = f.read(12)
+        return h[:4] == b"RIFF" and h[8:12] == b"WAVE"
+    except OSError:
+        return False
+
+
 def default_stem_loader(path):
+    """torchaudio.load when torchaudio is installed (what the reference calls, src/data.py:171); otherwise PCM RIFF
+    files are read directly -- recognised by CONTENT, so pre-decoded stems may keep the `{stem}.mp3` names the reference
+    hard-codes (src/data.py:188).  Compressed audio without torchaudio is an error, never a silent fallback."""
     try:
         import torchaudio  # noqa: F401
         return torchaudio.load(path)
     except ImportError:
-        if path.lower().endswith(".wav"):
+        if _is_riff(path):
             return _load_wav(path)
-        raise RuntimeError(f"cannot decode {path}: torchaudio is not installed; pass stem_loader= or use .wav stems")
+        raise RuntimeError(f"cannot decode {path}: torchaudio is not installed; pass stem_loader= or use PCM .wav stems")
+
+
+def _clip_features(ds, clip_stems):
+    """Features slot of one clip: the real vector (`compute_features=True`, needs a usable GPU context in this
+    process) or the deferred placeholder row the model fills in on the device (default; "auto" is an alias)."""
+    if ds.compute_features is True:
+        dev = ds.device or "cuda"
+        return ds.feature_extractor.extract_all_features({k: v.to(dev) for k, v in clip_stems.items()}).cpu()
+    if ds.compute_features not in ("deferred", "auto", False, None):
+        raise ValueError(f"compute_features={ds.compute_features!r}: expected True or 'deferred'")
+    return deferred_features(ds.feature_extractor.get_feature_dim())
 
 
 class FMABaselineDataset(Dataset):
     """Pre-separated stems, positive pairs = different temporal segments of one song (reference src/data.py:111-288)."""
 
     def __init__(self, separated_path="/nas/FMA/fma_separated/", clip_duration=10.0, sample_rate=44100, n_fft=1024,
-                 hop_length=256, n_mels=128, num_segments=2, min_audio_duration=25.0, compute_features="auto",
+                 hop_length=256, n_mels=128, num_segments=2, min_audio_duration=25.0, compute_features="deferred",
                  stem_loader=None, stem_ext=".mp3", device=None):
         self.separated_path = separated_path
         self.clip_duration = clip_duration
@@ -132,13 +158,7 @@ class FMABaselineDataset(Dataset):
         return stems
 
     def _features(self, clip_stems):
-        mode = self.compute_features
-        if mode == "auto":
-            mode = torch.cuda.is_initialized() if torch.cuda.is_available() else False
-        if not mode:
-            return None
-        dev = self.device or "cuda"
-        return self.feature_extractor.extract_all_features({k: v.to(dev) for k, v in clip_stems.items()}).cpu()
+        return _clip_features(self, clip_stems)
 
     def _crop_starts(self, audio_length):
         """numpy global-RNG draws in the reference's order (src/data.py:222-266)."""
@@ -179,8 +199,9 @@ class FMABaselineDataset(Dataset):
 
 
 def baseline_collate_fn(batch):
-    """List of (stems_list, features_list, song_idx, track_dir) -> (stems_dict {stem: (N,2,T)}, features (N,F) or None
-    when the features are deferred to the device, song_labels (N,) int64, track_dirs [N]).  reference src/data.py:291-328"""
+    """List of (stems_list, features_list, song_idx, track_dir) -> (stems_dict {stem: (N,2,T)}, features (N,F) (rows may
+    be deferred placeholders, see mixing_utils.FEATURES_DEFERRED), song_labels (N,) int64, track_dirs [N]).
+    reference src/data.py:291-328"""
     stems, feats, labels, dirs = [], [], [], []
     for stems_list, features_list, song_idx, track_dir in batch:
         for s, f in zip(stems_list, features_list):
@@ -189,8 +210,7 @@ def baseline_collate_fn(batch):
             labels.append(song_idx)
             dirs.append(track_dir)
     stems_dict = {name: torch.stack([s[name] for s in stems], dim=0) for name in STEMS}
-    features = None if any(f is None for f in feats) else torch.stack(feats, dim=0)
-    return stems_dict, features, torch.tensor(labels, dtype=torch.long), dirs
+    return stems_dict, torch.stack(feats, dim=0), torch.tensor(labels, dtype=torch.long), dirs
 
 
 def shard_batch(stems_dict, features, song_labels, rank, world_size):
@@ -206,12 +226,13 @@ class StyleTransferDataset(Dataset):
     src/data.py:331-538, on the same feature kernels.  numpy global-RNG draws in the reference's order:
     input crop `randint(0, L - C)` (only when L > C; upper bound exclusive, :481-482), target index `randint(0, len)`
     redrawn while equal to idx (:516-519), target crop.  Short tracks are zero-padded (:471-477).
-    `compute_features` as in FMABaselineDataset: features need the device, so fork'd workers return None and the
-    batch's target features come from `MixingFeatureExtractor.extract_all_features(target_stems_dict)` on the GPU."""
+    `compute_features` as in FMABaselineDataset: by default the target-features slot is a deferred placeholder row
+    that `MixingStyleEncoder.forward(target_stems, target_features)` (src/train_style_transfer.py:206-211) fills in on
+    the device; `feature_extractor.resolve_features(target_stems, target_features)` does the same outside the model."""
 
     def __init__(self, data_path=None, separated_path="/nas/FMA/fma_separated/", use_preseparated=True,
                  scnet_separator=None, clip_duration=10.0, sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128,
-                 use_detailed_spectral=False, n_spectral_bins=32, compute_features="auto", stem_loader=None,
+                 use_detailed_spectral=False, n_spectral_bins=32, compute_features="deferred", stem_loader=None,
                  stem_ext=".mp3", audio_loader=None, device=None):
         self.data_path, self.separated_path, self.use_preseparated = data_path, separated_path, use_preseparated
         self.scnet = scnet_separator
@@ -271,20 +292,12 @@ class StyleTransferDataset(Dataset):
         while target_idx == idx:
             target_idx = int(np.random.randint(0, len(self)))
         target_stems = self._random_crop_stems(self._load_full(target_idx), self.clip_samples)
-        mode = self.compute_features
-        if mode == "auto":
-            mode = torch.cuda.is_initialized() if torch.cuda.is_available() else False
-        feats = None
-        if mode:
-            dev = self.device or "cuda"
-            feats = self.feature_extractor.extract_all_features({k: v.to(dev) for k, v in target_stems.items()}).cpu()
-        return input_stems, target_stems, feats
+        return input_stems, target_stems, _clip_features(self, target_stems)
 
 
 def style_transfer_collate_fn(batch):
-    """[(input_stems, target_stems, target_features)] -> (input {stem: (B,2,T)}, target {stem: (B,2,T)}, (B,F) | None)
+    """[(input_stems, target_stems, target_features)] -> (input {stem: (B,2,T)}, target {stem: (B,2,T)}, (B,F))
     reference src/data.py:541-578."""
     inp = {s: torch.stack([b[0][s] for b in batch], 0) for s in STEMS}
     tgt = {s: torch.stack([b[1][s] for b in batch], 0) for s in STEMS}
-    feats = None if any(b[2] is None for b in batch) else torch.stack([b[2] for b in batch], 0)
-    return inp, tgt, feats
+    return inp, tgt, torch.stack([b[2] for b in batch], 0)

@@ -15,6 +15,34 @@ from . import _lib
 
 STEMS = ("vocals", "bass", "drums", "other")
 
+# Deferred mixing features.  The reference computes the features in the Dataset, inside fork'd DataLoader workers on the
+# CPU (src/data.py:231-265); a HIP context cannot be used after fork, so a worker hands out a PLACEHOLDER row instead --
+# a real (feature_dim,) fp32 tensor, every element FEATURES_DEFERRED -- and `MixingStyleEncoder.forward` fills such rows
+# on the device from the same stage-A launch that produces the model's log-mel (one pass over the waveform).  Real
+# features are clamped to [-100, 100] (src/mixing_utils.py:338-341), so the marker cannot collide with a value; it is
+# finite (train.py:237's isnan check stays quiet) and exact in fp32 / fp16 / bf16.
+FEATURES_DEFERRED = -32768.0
+
+
+def deferred_features(feature_dim: int) -> torch.Tensor:
+    return torch.full((feature_dim,), FEATURES_DEFERRED, dtype=torch.float32)
+
+
+def is_deferred(features: torch.Tensor) -> torch.Tensor:
+    """(..., F) -> (..., 1) bool: rows that are placeholders (decided on the tensor's own device, no host sync)."""
+    return features[..., :1] == FEATURES_DEFERRED
+
+
+def detailed_bins_for_feature_dim(feature_dim: int):
+    """Inverse of MixingFeatureExtractor.get_feature_dim (src/mixing_utils.py:53-69): 4*(6+sd+3)+8 with sd = 5 (default)
+    or n_spectral_bins + 2 (detailed mode).  -> n_spectral_bins (0 = default layout) or None if no layout has this size."""
+    if feature_dim < 8 or (feature_dim - 8) % 4:
+        return None
+    sd = (feature_dim - 8) // 4 - 9
+    if sd == 5:
+        return 0
+    return sd - 2 if sd >= 3 else None
+
 
 def hann_window(n_fft: int) -> torch.Tensor:
     return torch.hann_window(n_fft, periodic=True, dtype=torch.float32)
@@ -176,6 +204,12 @@ class MixingFeatureExtractor:
         """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F))."""
         lm, f = self.plan().forward_stems(stems_dict, True, True)
         return f, lm
+
+    def resolve_features(self, stems_dict, features):
+        """Fill the placeholder rows of `features` (see FEATURES_DEFERRED) from the stems, on the stems' device."""
+        f = self.extract_all_features(stems_dict)
+        features = features.to(f.device)
+        return torch.where(is_deferred(features), f, features.to(f.dtype))
 
     def extract_all_features(self, stems_dict):
         """stems_dict {stem: (2,T)} -> (feature_dim,)  [reference]; {stem: (B,2,T)} -> (B, feature_dim)."""

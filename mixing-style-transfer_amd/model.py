@@ -15,13 +15,15 @@ Forward paths
 import ctypes as C
 
 import os
+import warnings
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .mixing_utils import STEMS, MelFeatPlan, hann_window, melscale_fbanks_htk, stems_to_tensor
+from .mixing_utils import (STEMS, MelFeatPlan, detailed_bins_for_feature_dim, hann_window, is_deferred,
+                           melscale_fbanks_htk, stems_to_tensor)
 
 
 class _Buf(nn.Module):
@@ -47,17 +49,19 @@ class MelSpectrogramPreprocessor(nn.Module):
         super().__init__()
         self.sample_rate, self.n_fft, self.hop_length, self.n_mels = sample_rate, n_fft, hop_length, n_mels
         self.mel_transform = _MelTransform(sample_rate, n_fft, n_mels)
-        self._plan = None
+        self._plans = {}
 
-    def plan(self) -> MelFeatPlan:
-        if self._plan is None:  # built from the module's own buffers, so a loaded checkpoint's tables are honoured
-            self._plan = MelFeatPlan(self.sample_rate, self.n_fft, self.hop_length, self.n_mels, 0,
-                                     self.mel_transform.spectrogram.window, self.mel_transform.mel_scale.fb)
-        return self._plan
+    def plan(self, detailed_bins=0) -> MelFeatPlan:
+        """Stage-A plan; `detailed_bins` selects the feature layout the same launch can emit next to the log-mel."""
+        if detailed_bins not in self._plans:  # built from the module's own buffers: a loaded checkpoint's tables are honoured
+            self._plans[detailed_bins] = MelFeatPlan(self.sample_rate, self.n_fft, self.hop_length, self.n_mels,
+                                                     detailed_bins, self.mel_transform.spectrogram.window,
+                                                     self.mel_transform.mel_scale.fb)
+        return self._plans[detailed_bins]
 
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)
-        self._plan = None
+        self._plans = {}
 
     def forward(self, stems_dict):
         lm, _ = self.plan().forward_stems(stems_dict, True, False)
@@ -475,7 +479,9 @@ class MixingStyleEncoder(nn.Module):
         self._hip_train = None
         # training (grad enabled, model.train()): "hip" = conv trunk forward + pool/ReLU/FiLM/BatchNorm backward in libmst.so
         # (see _HipTrunk; 52 ms vs 98 ms per 72-clip step); "torch" = everything on PyTorch-ROCm autograd
+        # "hip-strict" = as "hip", but raise instead of warning when a call cannot take the hand-written trunk
         self.train_backend = "hip"
+        self._warned = set()
 
     def _params_version(self):
         return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
@@ -517,40 +523,54 @@ class MixingStyleEncoder(nn.Module):
         x = F.dropout(pool_in, cn[0].dropout2.p, self.training)
         return ae.attention_pooling(x)
 
+    def _hip_trunk_refusal(self, logmel):
+        """Why the hand-written training trunk cannot take this call (None = it can)."""
+        if self.audio_encoder.split_size // 10 not in (1, 2):
+            return f"split_size={self.audio_encoder.split_size}: the training kernels cover first-pool heights 1 and 2"
+        if not logmel.is_cuda:
+            return "log-mel is not on the GPU"
+        if logmel.shape[-1] < 20:
+            return f"{logmel.shape[-1]} frames < 20"
+        if logmel.dtype != torch.float32 or self.film_encoder.film_head.weight.dtype != torch.float32:
+            return f"non-fp32 tensors (log-mel {logmel.dtype}, parameters {self.film_encoder.film_head.weight.dtype})"
+        return None
+
     def forward_from_logmel(self, logmel, mixing_features):
-        if self.encoder_backend == "hip" and self.training and self.train_backend == "hip" and \
-                self._needs_autograd(mixing_features) and self.audio_encoder.split_size // 10 in (1, 2) and \
-                logmel.is_cuda and logmel.shape[-1] >= 20 and logmel.dtype == torch.float32 and \
-                self.film_encoder.film_head.weight.dtype == torch.float32:
-            return self._forward_train_hip(logmel, mixing_features)
-        if self.encoder_backend == "hip" and not self._needs_autograd(mixing_features):
+        auto = self._needs_autograd(mixing_features)
+        if self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict"):
+            why = self._hip_trunk_refusal(logmel)
+            if why is None:
+                return self._forward_train_hip(logmel, mixing_features)
+            msg = (f"MixingStyleEncoder: training forward leaves the hand-written HIP trunk ({why}); running the conv stack "
+                   f"on PyTorch-ROCm/MIOpen autograd instead (about 2x the step time, library numerics)")
+            if self.train_backend == "hip-strict":
+                raise RuntimeError(msg)
+            if why not in self._warned:
+                self._warned.add(why)
+                warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        if self.encoder_backend == "hip" and not auto:
             if self.training:
                 raise RuntimeError("HIP encoder forward implements eval-mode BatchNorm/Dropout; call model.eval() "
-                                   "or enable grad for the PyTorch-ROCm training path")
+                                   "or enable grad for the training path")
             return self.hip_encoder().forward(logmel, mixing_features)
         return self.audio_encoder.forward_from_logmel(logmel, self.film_encoder(mixing_features))
 
     def forward(self, stems_dict, mixing_features):
+        """reference src/model.py:508-542.  ONE stage-A launch over the waveform yields the log-mel and the mixing
+        features; rows of `mixing_features` that are deferred placeholders (what the Dataset hands out from fork'd
+        workers, mixing_utils.FEATURES_DEFERRED) are filled from it on the device -- no host sync -- and rows that
+        hold real values are used as given."""
+        bins = detailed_bins_for_feature_dim(self.film_encoder.feature_dim)
+        pre = self.audio_encoder.mel_preprocessor
         with torch.no_grad():
-            logmel = self.audio_encoder.mel_preprocessor(stems_dict)
-        return self.forward_from_logmel(logmel, mixing_features)
-
-
-def _smoke():
-    """One tiny end-to-end forward on cuda:0 checked against the CPU oracle (called by __graft_entry__.smoke)."""
-    from oracle import encoder as oenc
-    from oracle import features as ofeat
-    from .synth import synth_batch
-    torch.manual_seed(0)
-    m = MixingStyleEncoder(feature_dim=64).cuda().eval()
-    x = synth_batch(2, 33075)
-    stems = {s: x[:, 2 * i:2 * i + 2].cuda() for i, s in enumerate(STEMS)}
-    from .mixing_utils import MixingFeatureExtractor
-    feats = MixingFeatureExtractor().extract_all_features(stems)
-    with torch.no_grad():
-        emb = m(stems, feats).cpu()
-    sd = {k: v.cpu() for k, v in m.state_dict().items()}
-    ref = oenc.encoder_forward(sd, x, ofeat.extract_all_features(x))
-    err = (emb - ref).abs().max().item() / ref.abs().max().item()
-    print(f"smoke: embedding err {err:.2e} (rel to max)")
-    assert err < 2e-4
+            if bins is not None and (bins == 0 or bins <= self.audio_encoder.n_mels):
+                logmel, feats = pre.plan(bins).forward_stems(stems_dict, True, True)
+            else:   # no feature layout of this size exists: the caller must bring real features
+                logmel, feats = pre(stems_dict), None
+        mf = mixing_features.to(logmel.device)
+        if feats is not None:
+            mf = torch.where(is_deferred(mf), feats.to(mf.dtype), mf)
+        elif bool(is_deferred(mf).any()):
+            raise ValueError(f"mixing_features holds deferred placeholder rows but feature_dim="
+                             f"{self.film_encoder.feature_dim} is not a MixingFeatureExtractor layout")
+        return self.forward_from_logmel(logmel, mf)

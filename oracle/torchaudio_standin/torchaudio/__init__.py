@@ -16,5 +16,18 @@ from . import transforms  # noqa: F401
 __version__ = "0.0-standin"
 
 
-def load(*a, **k):  # pragma: no cover - data.py cannot import here anyway (SCNet absent)
-    raise RuntimeError("torchaudio stand-in: load() is not provided")
+def load(path, *a, **k):
+    """16-bit PCM RIFF reader -> (float32 tensor (channels, frames) scaled by 1/32768, sample_rate), what
+    torchaudio.load(normalize=True) returns for such a file.  Used only to let the reference's src/data.py read the
+    toy stems of tests/golden/make_golden.py::gen_dataset (RIFF bytes under the hard-coded `{stem}.mp3` names)."""
+    import wave
+
+    import numpy as np
+    import torch
+    with wave.open(str(path), "rb") as w:
+        ch, sw, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        if sw != 2:
+            raise RuntimeError("torchaudio stand-in: 16-bit PCM only")
+        raw = w.readframes(n)
+    a = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    return torch.from_numpy(a.reshape(-1, ch).T.copy()), sr

@@ -155,3 +155,58 @@ def song_a_clips():
         x = torch.from_numpy(g[k].astype(np.float32) / 32768.0)   # (2, 441000)
         out.append(pseudo_separate(x))
     return torch.stack(out, 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Toy pre-separated track directories for the dataset / retrieval fixtures (tests/golden/dataset.npz)
+# ---------------------------------------------------------------------------------------------------------------
+TOY_CLIP = 11025            # 0.25 s at 44.1 kHz
+TOY_TRACKS = {              # name -> (length in samples, channels per stem file); lengths vs C=11025: >2C, ==2C, <2C, <C
+    "a_long": (30000, 2), "b_exact2c": (22050, 2), "c_lt2c": (15000, 2), "d_ltc": (8000, 2), "e_mono": (26000, 1)}
+
+
+def toy_track_pcm(name):
+    """int16 (8, L) stems of a toy track (mono tracks: R == L)."""
+    L, ch = TOY_TRACKS[name]
+    x = synth_clip(100 + sorted(TOY_TRACKS).index(name), L)
+    q = torch.round(x * 32767.0).to(torch.int16)
+    if ch == 1:
+        q[1::2] = q[0::2]
+    return q
+
+
+def write_toy_tracks(root, ext=".mp3"):
+    """One directory per toy track holding {stem}{ext} as 16-bit PCM RIFF bytes (the reference hard-codes the `.mp3`
+    names, src/data.py:188; the fixture generator reads them through a RIFF-reading stand-in)."""
+    import wave
+    for name, (L, ch) in TOY_TRACKS.items():
+        d = os.path.join(root, name)
+        os.makedirs(d, exist_ok=True)
+        q = toy_track_pcm(name)
+        for i, s in enumerate(STEMS):
+            a = q[2 * i:2 * i + ch].T.contiguous().numpy().astype("<i2")
+            with wave.open(os.path.join(d, s + ext), "wb") as w:
+                w.setnchannels(ch)
+                w.setsampwidth(2)
+                w.setframerate(44100)
+                w.writeframes(a.tobytes())
+    return root
+
+
+class RandintLog:
+    """Context manager that records every np.random.randint(low, high) call made inside it as (low, high, result)."""
+
+    def __enter__(self):
+        import numpy as np
+        self.np, self.real, self.calls = np, np.random.randint, []
+
+        def logged(low, high=None, *a, **k):
+            v = self.real(low, high, *a, **k)
+            self.calls.append((int(low), -1 if high is None else int(high), int(v)))
+            return v
+        np.random.randint = logged
+        return self
+
+    def __exit__(self, *exc):
+        self.np.random.randint = self.real
+        return False

@@ -21,3 +21,11 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    import parity
+    if parity.ROWS:
+        for line in parity.summary_lines():
+            terminalreporter.write_line(line)
+        parity.dump()

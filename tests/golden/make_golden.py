@@ -3,8 +3,9 @@
 Usage (build container only; /root/reference does not exist on the GPU box):
     python tests/golden/make_golden.py
 
-Imports /root/reference/src/{mixing_utils,model,loss}.py unmodified, with the stand-in
-`torchaudio` of oracle/torchaudio_standin on sys.path (torchaudio is not installed here).
+Imports /root/reference/src/{mixing_utils,model,loss,data,validation_utils}.py unmodified, with the stand-in
+`torchaudio` of oracle/torchaudio_standin on sys.path (torchaudio is not installed here) and, for data.py /
+validation_utils.py, the empty-shell `librosa` / SCNet `utils.*` modules of oracle/ref_import_standins.
 Writes small .npz fixtures next to this file.  Inputs are NOT stored: tests rebuild them
 from tests/cases.py seeds and verify the stored input checksums.
 """
@@ -20,6 +21,7 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle", "torchaudio_standin"))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_import_standins"))   # librosa, SCNet `utils.*` shells (README there)
 sys.path.insert(0, "/root/reference/src")
 
 import cases  # noqa: E402
@@ -236,8 +238,96 @@ def gen_song_a():
     np.savez_compressed(os.path.join(HERE, "song_a.npz"), **out)
 
 
+def gen_dataset():
+    """SURVEY 8 a2-a4 + f3 from the reference's own src/data.py and src/validation_utils.py: numpy-RNG draw traces, clip
+    checksums, features and collated batches of FMABaselineDataset / StyleTransferDataset on the toy tracks of
+    tests/cases.py, retrieval metrics on seeded embeddings, and an embedding cache built by the reference loop."""
+    import tempfile
+    import data as ref_data                      # reference src/data.py
+    import validation_utils as ref_vu            # reference src/validation_utils.py
+    out = {}
+    names = sorted(cases.TOY_TRACKS)
+    cat8 = lambda d: torch.cat([d[s] for s in cases.STEMS], 0)  # noqa: E731
+    with tempfile.TemporaryDirectory() as root:
+        cases.write_toy_tracks(root)
+        # --- FMABaselineDataset: crop starts, clips, features, collate (src/data.py:201-328)
+        for nseg in (1, 2):
+            ds = ref_data.FMABaselineDataset(root, clip_duration=0.25, num_segments=nseg)
+            assert ds.clip_samples == cases.TOY_CLIP and len(ds) == len(names)
+            where = {os.path.basename(d): i for i, d in enumerate(ds.track_dirs)}
+            np.random.seed(42)
+            with cases.RandintLog() as log:
+                items = [ds[where[n]] for n in names]
+            out[f"fma{nseg}.randint"] = np.array(log.calls, dtype=np.int64).reshape(-1, 3)
+            out[f"fma{nseg}.clips_per_item"] = np.array([len(it[0]) for it in items])
+            out[f"fma{nseg}.clip_checksum"] = np.array([cases.checksum(cat8(c)) for it in items for c in it[0]])
+            out[f"fma{nseg}.clip_head"] = np.stack([cat8(c)[:, :4].numpy() for it in items for c in it[0]])
+            out[f"fma{nseg}.features"] = np.stack([f.numpy() for it in items for f in it[1]])
+            out[f"fma{nseg}.item_track"] = np.array([os.path.basename(it[3]) for it in items])
+            assert all(it[2] == where[os.path.basename(it[3])] for it in items)
+            sd, feats, labels, dirs = ref_data.baseline_collate_fn(items)
+            out[f"fma{nseg}.collate_feature_shape"] = np.array(feats.shape)
+            out[f"fma{nseg}.collate_label_track"] = np.array([names[[where[n] for n in names].index(int(l))] for l in labels])
+            out[f"fma{nseg}.collate_dir_track"] = np.array([os.path.basename(d) for d in dirs])
+            out[f"fma{nseg}.collate_checksum"] = np.array([cases.checksum(sd[s]) for s in cases.STEMS])
+            out[f"fma{nseg}.collate_dtype"] = np.array([str(labels.dtype), str(feats.dtype), str(sd["bass"].dtype)])
+            assert torch.equal(feats, torch.stack([f for it in items for f in it[1]]))
+        # bad num_segments: the reference's error text
+        try:
+            ref_data.FMABaselineDataset(root, clip_duration=0.25, num_segments=3)[0]
+        except ValueError as e:
+            out["fma.bad_segments_error"] = np.array(str(e))
+        # --- StyleTransferDataset draw order (src/data.py:467-538)
+        st = ref_data.StyleTransferDataset(None, root, clip_duration=0.4)
+        where = {os.path.basename(d): i for i, d in enumerate(st.track_dirs)}
+        order = ["a_long", "c_lt2c", "e_mono", "d_ltc", "b_exact2c", "a_long"]
+        np.random.seed(7)
+        with cases.RandintLog() as log:
+            items = [st[where[n]] for n in order]
+        # the target-index draws depend on the directory listing order: store them as names
+        out["st.order"] = np.array(order)
+        out["st.listing"] = np.array([os.path.basename(d) for d in st.track_dirs])
+        out["st.randint"] = np.array(log.calls, dtype=np.int64).reshape(-1, 3)
+        out["st.input_checksum"] = np.array([cases.checksum(cat8(it[0])) for it in items])
+        out["st.target_checksum"] = np.array([cases.checksum(cat8(it[1])) for it in items])
+        out["st.target_features"] = np.stack([it[2].numpy() for it in items])
+        i_sd, t_sd, tf = ref_data.style_transfer_collate_fn(items)
+        out["st.collate_checksum"] = np.array([cases.checksum(i_sd[s]) + cases.checksum(t_sd[s]) for s in cases.STEMS])
+        out["st.collate_feature_shape"] = np.array(tf.shape)
+        # --- segment loading + embedding cache through the reference loop (src/validation_utils.py:15-74,106-214)
+        seg = ref_vu.load_stems_segment(os.path.join(root, "c_lt2c"), 0.2, 0.25, 44100)   # runs past the end: zero padded
+        out["vu.segment_shape"] = np.array(seg["drums"].shape)
+        out["vu.segment_checksum"] = np.array(cases.checksum(torch.from_numpy(np.concatenate([seg[s] for s in cases.STEMS]))))
+        seg = ref_vu.load_stems_segment(os.path.join(root, "e_mono"), 0.1, 0.25, 44100)    # mono stems -> stereo
+        out["vu.segment_mono_checksum"] = np.array(cases.checksum(torch.from_numpy(np.concatenate([seg[s] for s in cases.STEMS]))))
+        cfg = cases.CFG_DEFAULT
+        m = ref_model.MixingStyleEncoder(channels=8, feature_dim=64, **cfg).eval()
+        full = dict(m.state_dict())
+        full.update(cases.make_state_dict(cfg, seed=42))
+        m.load_state_dict(full, strict=True)
+        ds = ref_data.FMABaselineDataset(root, clip_duration=0.25)
+        where = {os.path.basename(d): i for i, d in enumerate(ds.track_dirs)}
+        cache = ref_vu.build_embedding_cache(ds, [where[n] for n in names], m, ds.feature_extractor, None,
+                                             torch.device("cpu"), query_duration=0.5)
+        out["vu.cache_tracks"] = np.array([os.path.basename(p) for p in cache["track_paths"]])
+        out["vu.cache_embeddings"] = cache["embeddings"].numpy()
+        assert cache["track_indices"] == [where[n] for n in names]
+    # --- retrieval metric on seeded embeddings (src/validation_utils.py:217-282)
+    g = torch.Generator().manual_seed(3)
+    pool = torch.randn(40, 32, generator=g)
+    pool_idx = list(range(100, 140))
+    q_idx = [100 + i for i in range(0, 40, 2)]
+    queries = torch.stack([pool[i - 100] + 2.0 * torch.randn(32, generator=g) for i in q_idx])
+    met = ref_vu.evaluate_retrieval_accuracy(queries, pool, q_idx, pool_idx, [1, 3, 5])
+    out["ret.in_checksum"] = np.array(cases.checksum(pool) + cases.checksum(queries))
+    out["ret.metrics"] = np.array([met["top_1_accuracy"], met["top_3_accuracy"], met["top_5_accuracy"]])
+    ti, ts = ref_vu.retrieve_top_k(queries[0], pool, k=5)
+    out["ret.top5_idx"], out["ret.top5_sim"] = ti.numpy(), ts.numpy()
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fbanks", "features", "logmel", "encoder", "infonce", "augment", "song_a"]
+    which = sys.argv[1:] or ["fbanks", "features", "logmel", "encoder", "infonce", "augment", "song_a", "dataset"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -1,0 +1,48 @@
+"""GPU: bench.py end to end on small shapes -- the contract line's keys, BASELINE configs[1] (`--encoder torch`, which
+crashed after timing in round 1), and `--gpus 2` launching its own two ranks (both on the box's single GPU, gloo for the
+exchange: RCCL refuses two ranks on one device; the control flow, sharding and gather are the same)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "2", "--warmup", "1", "--triplets", "2", "--seconds", "2", "--no-cpu-baseline"]
+
+
+def _bench(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_contract_line_hip_encoder():
+    out = _bench(SMALL)
+    assert out["n_gpus"] == 1 and out["world"] == 1 and out["unit"] == "triplets/s" and out["value"] > 0
+    rf = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "stage_a_hbm_frac", "stage_b_tflops",
+              "stage_b_tflops_algorithmic", "fused_hbm_frac"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and 0 < rf["stage_a_hbm_frac"] < 1
+    assert rf["stage_b_tflops"] <= rf["stage_b_tflops_algorithmic"] < 157.3       # executed <= reference's flop count
+    assert "alt" in out and isinstance(out["alt"], list)
+
+
+def test_configs1_torch_encoder_line():
+    out = _bench(SMALL + ["--encoder", "torch"])
+    assert "configs[1]" in out["config"]["workload"] and out["config"]["encoder_backend"] == "torch"
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["traffic"] is None
+
+
+def test_gpus_2_launches_two_ranks_itself():
+    out = _bench(["--gpus", "2"] + SMALL, MST_BENCH_ONE_GPU="1", MST_BENCH_BACKEND="gloo")
+    assert out["n_gpus"] == 2 and out["world"] == 2 and out["rccl_ranks_seen"] == 2
+    assert out["config"]["parallelism"] == "clip-sharded x2" and "cpu_baseline" not in out

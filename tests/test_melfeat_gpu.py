@@ -11,6 +11,7 @@ import pytest
 import torch
 
 import cases
+import parity
 from oracle import features as ofeat
 from oracle import mel as omel
 
@@ -53,18 +54,24 @@ def fft_noise_unit(x, sample_rate=44100, n_fft=1024, hop=256, n_mels=128):
     return unit, torch.log(mel64 + 1e-10)
 
 
-def check_logmel(lm, ref, tol=1e-4, x=None, cfg=None):
+def check_logmel(lm, ref, tol=1e-4, x=None, cfg=None, name="log-mel"):
     """|gpu - ref| <= tol * max(1, |ref|).  When the input x is given the bound is made principled for
     ill-conditioned inputs: bins far below the frame's spectral peak (a low-passed bass stem of real music, a large DC
     offset) carry the fp32 FFT's rounding noise inside log(mel + 1e-10) in ANY fp32 implementation -- on real music
     (tests/golden/song_a_crops.npz) the reference's own CPU result is up to 0.12 (natural-log units) away from the
     float64 result and 8 % of its bins are off by more than 1e-4.  With unit = fft_noise_unit(x) (conditioning of
-    each bin, computed from the input alone) and z = |result - float64 result| / unit:
+    each bin, computed from the input alone) and z = (|result - float64 result| - tol * max(1, |ref|)) / unit, the
+    noise a result carries MEASURED in units:
       * where 64 * unit <= 0.2 * tol (well-conditioned bins): strict |gpu - fp32 oracle| <= tol * max(1, |ref|);
-      * everywhere: |gpu - float64| <= tol * max(1, |ref|) + 256 * unit   (the fp32 oracle itself needs ~110 units);
-      * over the bins with unit > 1e-5: rms(z_gpu) <= 2 * rms(z_oracle32) + 1 -- the kernel is no noisier than twice
-        the reference's own FFT."""
+      * everywhere: max z_gpu <= 1.5 * max(max z_oracle32, 8) -- the kernel's worst bin needs at most 1.5x the noise
+        allowance the reference's own fp32 FFT (pocketfft) needs on the same input;
+      * over the bins with unit > 1e-5: rms(|gpu - f64| / unit) <= 2 * rms(|oracle32 - f64| / unit) + 1.
+    Every call records the error distribution (tests/parity.py)."""
+    import inspect
+    fr = inspect.stack()[1]
+    name = f"{fr.function.replace('test_', '')[:34]}:{fr.lineno} {name}"
     e32 = scaled_err(lm, ref)
+    parity.record(name + " vs fp32 ref", lm, ref, floor_abs=1.0)
     if x is None:
         assert e32 <= tol, f"log-mel max scaled err {e32:.3e}"
         return
@@ -77,16 +84,24 @@ def check_logmel(lm, ref, tol=1e-4, x=None, cfg=None):
     if well.any():
         assert (g32[well] / den[well]).max().item() <= tol, \
             f"log-mel err vs fp32 oracle on well-conditioned bins {(g32[well] / den[well]).max().item():.3e}"
-    excess = (g64 - tol * den - 256 * unit).max().item()
-    assert excess <= 0, f"log-mel err vs float64 exceeds tol + 256 noise units by {excess:.3e}"
+    zg_max = ((g64 - tol * den) / unit).max().item()
+    zr_max = ((r64 - tol * den) / unit).max().item()
     live = unit > 1e-5   # bins where FFT noise, not the rounding of log() itself, is what is being measured
+    zg = zr = 0.0
     if live.any():
         zg = (g64[live] / unit[live]).pow(2).mean().sqrt().item()
         zr = (r64[live] / unit[live]).pow(2).mean().sqrt().item()
-        assert zg <= 2.0 * zr + 1.0, f"rms noise (units): gpu {zg:.2f} vs fp32 oracle {zr:.2f}"
+    parity.note(name + " FFT noise (units of 2^-24 |frame|)", gpu_max=zg_max, oracle32_max=zr_max, gpu_rms=zg,
+                oracle32_rms=zr, well_conditioned_frac=float(well.double().mean()))
+    assert zg_max <= 1.5 * max(zr_max, 8.0), \
+        f"log-mel worst-bin noise: gpu needs {zg_max:.1f} units, the fp32 oracle {zr_max:.1f}"
+    assert zg <= 2.0 * zr + 1.0, f"rms noise (units): gpu {zg:.2f} vs fp32 oracle {zr:.2f}"
 
 
-def check_feats(f, ref, rtol=1e-4, atol=2e-4):
+def check_feats(f, ref, rtol=1e-4, atol=2e-4, name="features"):
+    import inspect
+    fr = inspect.stack()[1]
+    parity.record(f"{fr.function.replace('test_', '')[:34]}:{fr.lineno} {name}", f, ref, floor_abs=2.0)     # |d| <= 1e-4 |ref| + 2e-4  ==  rel <= 1e-4 with the floor at 2
     np.testing.assert_allclose(f.numpy().astype(np.float64), np.asarray(ref, dtype=np.float64), rtol=rtol, atol=atol)
 
 
