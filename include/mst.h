@@ -133,8 +133,9 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg,
                        const mst_encoder_weights* w);
 void mst_encoder_destroy(mst_encoder* enc);
 /* Optional: mode 1 runs conv1, mode 2 conv1 and conv2, on the f16 matrix cores with 3-term split precision
- * (x = xh + xl, w = wh + wl; xh*wh + xh*wl + xl*wh, fp32 accumulate; per-product error ~2^-22; mode 2 needs
- * max(pool1) < 65504).  Mode 3 runs both convolutions with plain f16 operands (xh * wh only, fp32 accumulate):
+ * (x = xh + xl, w = wh + wl; xh*wh + xh*wl + xl*wh, fp32 accumulate; per-product error ~2^-22).  conv2's f16 input is
+ * range-scaled per (clip, sub-band) by an exact power of two derived on the device from a bound on conv1's output
+ * (||w||_1 * max|log-mel| through the folded affine), so no activation magnitude overflows f16 and nothing is refused.  Mode 3 runs both convolutions with plain f16 operands (xh * wh only, fp32 accumulate):
  * the arithmetic of the reference's `--use_amp` autocast convolutions (src/train.py:251-253), ~1e-3 of fp32.
  * 0 (default) = exact fp32 MFMA.  Call before mst_encoder_workspace_bytes. */
 int mst_encoder_set_precision(mst_encoder* enc, int conv1_f16x3);

@@ -30,6 +30,17 @@ int fail(int code, const char* fmt, ...);
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// true the first time a call site runs on the CURRENT device: hipFuncSetAttribute (dynamic-LDS limit) is a per-device
+// setting, so a process that drives several GPUs has to repeat it on each of them.  `mask` is the call site's static.
+inline bool first_use_on_device(unsigned long long& mask) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (mask & bit) return false;
+  mask |= bit;
+  return true;
+}
+
 template <typename T>
 int upload(T** dst, const T* host, size_t n) {
   *dst = nullptr;

@@ -181,6 +181,9 @@ struct ConvParams {
   // accumulator-order layout of yraw (tile rows / columns of the 8 x 8 or SUB x 40 tiling it is indexed by) and the
   // first output row of this launch (MODE 3: the strip kernel scatters its 2-row tiles into the 8 x 8 layout)
   int acc_tr, acc_tc, row_off;
+  // split-precision f16 path: per-(clip, band) power-of-two scale of conv1's pooled output, [B][nsub][2] = (s, 1/s)
+  // (f16_scale_kernel); conv1 stores m * s as f16 hi/lo, conv2 folds 1/s into its affine.  NULL = unscaled.
+  const float* f16_scale;
 };
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
@@ -703,6 +706,58 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 // last 3 tap slots carry zero weights); the patch is stored channel-minor ([row][col][8 ch] f16, hi and lo) so an
 // A fragment is one ds_read_b128.  The default path stays the exact-fp32 kernel above.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Range control of the f16 split-precision path.  conv2 reads conv1's pooled activations as f16 (hi + lo); f16
+// saturates at 65504 and loses its low part below ~1e-1.  Instead of checking the range on the host, every
+// (clip, band) gets an exact power-of-two scale s from a rigorous bound, before conv1 runs:
+//     pooled = max(0, A_c * acc + C_c),  |acc| <= ||w_c||_1 * max|log-mel of the clip|
+//     bound  = max_c (|A_c| ||w_c||_1 xmax + |C_c|),   s = 2^(14 - ceil(log2 bound))   =>   s * pooled <= 2^14.
+// The bound is loose (typically 30-100x), which f16's floating exponent absorbs: values 2^-28 of the bound are still
+// normal.  s is exact in every format involved, so scaling changes no rounding except through the f16 range itself.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n_per_clip, unsigned* out) {
+  const float* base = x + (size_t)blockIdx.y * n_per_clip;
+  float m = 0.f;
+  const long long n4 = n_per_clip >> 2;
+  const float4* b4 = reinterpret_cast<const float4*>(base);
+  const bool al = (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+  if (al) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const float4 v = b4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_clip; i += (long long)gridDim.x * 256)
+      m = fmaxf(m, fabsf(base[i]));
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_per_clip; i += (long long)gridDim.x * 256)
+      m = fmaxf(m, fabsf(base[i]));
+  }
+  m = mst::wave_max(m);
+  // non-negative floats order like their bit patterns; a NaN / Inf input ends up as a huge pattern -> scale 2^-60
+  if ((threadIdx.x & 63) == 0) atomicMax(out + blockIdx.y, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(64) void f16_scale_kernel(const float2* __restrict__ aff1, const float* __restrict__ w1norm,
+                                                        const unsigned* __restrict__ xmax_bits, float* scale, int nsub) {
+  const int clip = blockIdx.x / nsub, band = blockIdx.x % nsub, c = threadIdx.x & 31;
+  const float xmax = __uint_as_float(xmax_bits[clip]);
+  const float2 a = aff1[((size_t)clip * nsub + band) * 32 + c];
+  float bound = fmaf(fabsf(a.x) * w1norm[band * 32 + c], xmax, fabsf(a.y));
+  bound = mst::wave_max(bound);
+  if (threadIdx.x == 0) {
+    int k = 0;
+    if (bound > 0.f && bound < INFINITY) {
+      int ex;
+      (void)frexpf(bound, &ex);          // bound = f * 2^ex, f in [0.5, 1)  =>  bound <= 2^ex
+      k = max(-60, min(60, 14 - ex));
+    } else if (!(bound < INFINITY)) {
+      k = -60;
+    }
+    scale[(size_t)blockIdx.x * 2] = ldexpf(1.0f, k);
+    scale[(size_t)blockIdx.x * 2 + 1] = ldexpf(1.0f, -k);
+  }
+}
+
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 constexpr float kF16Scale = 1024.0f;  // weight pre-scale (folded back in the epilogue)
 constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
@@ -873,6 +928,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
       float* orow = p.out + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT * p.out_rows * p.out_cols +
                     (size_t)cur.tr * p.out_cols;
+      const float f16s = p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2] : 1.0f;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int ch = n * 16 + j;
@@ -889,11 +945,12 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
           const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
           if (pc < p.out_cols) {
             if (p.out) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
-            if (out_hi) {  // conv2's split-precision input: [clip][band][row][col][32 ch] f16, hi and lo
+            if (out_hi) {  // conv2's split-precision input: [clip][band][row][col][32 ch] f16, hi and lo, range-scaled
               const size_t o = ((((size_t)cur.clip * p.nsub + cur.band) * p.out_rows + cur.tr) * p.out_cols + pc) * 32 + ch;
-              const _Float16 h = (_Float16)m;
+              const float ms = m * f16s;
+              const _Float16 h = (_Float16)ms;
               out_hi[o] = h;
-              if (TERMS == 3) out_lo[o] = (_Float16)(m - (float)h);
+              if (TERMS == 3) out_lo[o] = (_Float16)(ms - (float)h);
             }
           }
         }
@@ -1033,11 +1090,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     if (chunk == NCH - 1 && cur.valid) {
       const int j = lane & 15, g = lane >> 4;
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * 64;
+      const float inv_s = (1.0f / kF16Scale) * (p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2 + 1] : 1.0f);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int ch = n * 16 + j;
         float2 ac = aff[ch];
-        ac.x *= (1.0f / kF16Scale);
+        ac.x *= inv_s;   // undo the weight pre-scale and the input's range scale (both exact powers of two)
         float m = 0.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -1243,6 +1301,7 @@ struct mst_encoder {
   int num_cus = 256;
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
   void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
+  float* w1norm = nullptr;    // [nsub][32] L1 norm of every conv1 filter (range bound of the f16 path)
   int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3, 3 conv1 + conv2 plain f16 (amp)
   // un-folded parameters for the training forward (batch-statistics BatchNorm)
   float *c1b = nullptr, *bn1w = nullptr, *bn1b = nullptr, *c2b = nullptr, *bn2w = nullptr, *bn2b = nullptr;
@@ -1252,7 +1311,7 @@ struct mst_encoder {
 namespace {
 
 struct WsLayout {
-  size_t film, aff1, aff2, pool1, pool1_h16, pool1_l16, pool_in, scores, pooled, total;
+  size_t film, aff1, aff2, pool1, pool1_h16, pool1_l16, f16scale, xmax, pool_in, scores, pooled, total;
   int W1, W2;
 };
 
@@ -1273,6 +1332,8 @@ WsLayout ws_layout(const mst_encoder* e, int B, int frames) {
   L.pool1 = take((size_t)B * ns * 32 * e->H1 * L.W1 * 4);
   L.pool1_h16 = take(e->conv1_f16x3 >= 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
   L.pool1_l16 = take(e->conv1_f16x3 == 2 ? (size_t)B * ns * 32 * e->H1 * L.W1 * 2 : 0);
+  L.f16scale = take(e->conv1_f16x3 >= 2 ? (size_t)B * ns * 2 * 4 : 0);
+  L.xmax = take(e->conv1_f16x3 >= 2 ? (size_t)B * 4 : 0);
   L.pool_in = take((size_t)B * e->C * L.W2 * 4);
   L.scores = take((size_t)B * L.W2 * 4);
   L.pooled = take((size_t)B * e->C * 4);
@@ -2075,12 +2136,11 @@ template <int LAYER, int SUB>
 hipError_t launch_conv(const ConvParams& cp, int grid, hipStream_t st) {
   using GEO = ConvGeom<LAYER, SUB>;
   const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
-  static bool attr_set = false;  // one driver call per kernel per process, not per launch
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+  if (mst::first_use_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<LAYER, SUB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_kernel<LAYER, SUB>), dim3(grid), dim3(kConvThreads), lds, st, cp);
   return hipGetLastError();
@@ -2173,6 +2233,13 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
               g16[base + (size_t)lane * 8 + j] = h;
               g16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(wv - (float)h);
             }
+  std::vector<float> w1n((size_t)ns * 32);   // L1 norms of the conv1 filters, with a margin for the hi/lo rounding
+  for (int b = 0; b < ns; ++b)
+    for (int co = 0; co < 32; ++co) {
+      double a = 0.0;
+      for (int i = 0; i < 8 * 49; ++i) a += fabs((double)w->conv1_w[((size_t)b * 32 + co) * 392 + i]);
+      w1n[(size_t)b * 32 + co] = (float)(a * 1.001);
+    }
   int rc = 0;
   {
     _Float16 *d16 = nullptr, *e16 = nullptr;
@@ -2182,6 +2249,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   }
 #define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
 #define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
+  UP(w1norm, w1n);
   UP(w1frag, f1); UP(w2frag, f2); UP(s1, s1); UP(t1, t1); UP(s2, s2); UP(t2, t2);
   UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projfrag, pfrag); UP(att0frag, af);
   UPP(b0, w->mlp0_b, H); UPP(b3, w->mlp3_b, H); UPP(hb, w->head_b, ns * 192);
@@ -2217,6 +2285,7 @@ void mst_encoder_destroy(mst_encoder* e) {
                    e->bn2w, e->bn2b, e->w2dfrag};
   for (float* q : ptrs) (void)hipFree(q);
   (void)hipFree(e->w1frag16);
+  (void)hipFree(e->w1norm);
   (void)hipFree(e->w2frag16);
   delete e;
 }
@@ -2282,18 +2351,26 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     if (e->sub == 2 && e->conv1_f16x3) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
-      static bool attr16 = false;
-      if (!attr16) {
+      static unsigned long long attr16 = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr16)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
-        attr16 = true;
       }
       const bool both = e->conv1_f16x3 >= 2;
       if (both && !(taps && taps->pool1)) cp.out = nullptr;   // fp32 pool1 only when a tap asks for it
+      if (both) {   // range scale of conv2's f16 input from a rigorous bound (see f16_scale_kernel): no host check, no refusal
+        unsigned* xmax = reinterpret_cast<unsigned*>(ws + L.xmax);
+        float* fsc = reinterpret_cast<float*>(ws + L.f16scale);
+        MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
+        const long long npc = (long long)8 * e->cfg.n_mels * frames;
+        hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, npc, xmax);
+        hipLaunchKernelGGL(f16_scale_kernel, dim3(B * ns), dim3(64), 0, st, aff1, e->w1norm, xmax, fsc, ns);
+        cp.f16_scale = fsc;
+      }
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
       _Float16* oh = both ? reinterpret_cast<_Float16*>(ws + L.pool1_h16) : nullptr;
       _Float16* ol = e->conv1_f16x3 == 2 ? reinterpret_cast<_Float16*>(ws + L.pool1_l16) : nullptr;
@@ -2303,12 +2380,11 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     } else if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 attribute failed: %s", hipGetErrorString(err));
-        attr_set = true;
       }
       hipLaunchKernelGGL((conv1_resident_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp);
       err = hipGetLastError();
@@ -2333,16 +2409,16 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     hipError_t err;
     if (e->conv1_f16x3 >= 2) {
       constexpr size_t lds = (size_t)(kF16Steps * 4 * 2 * 64 + kConvWaves * 2 * 14 * 14) * 16;
-      static bool attr = false;
-      if (!attr) {
+      static unsigned long long attr = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 f16x3 attribute failed: %s", hipGetErrorString(err));
-        attr = true;
       }
+      cp.f16_scale = reinterpret_cast<const float*>(ws + L.f16scale);
       const h16x8* ih = reinterpret_cast<const h16x8*>(ws + L.pool1_h16);
       const h16x8* il = reinterpret_cast<const h16x8*>(ws + L.pool1_l16);
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w2frag16);
@@ -2470,23 +2546,21 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     if (e->sub == 2) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (train) attribute failed: %s", hipGetErrorString(err));
-        attr_set = true;
       }
       hipLaunchKernelGGL((conv1_resident_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     } else {   // 10..19-mel sub-bands (pool height 1): the chunked kernel with the raw epilogue
       using GEO = ConvGeom<1, 1>;
       const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<1, 1, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (train) attribute failed: %s", hipGetErrorString(err));
-        attr_set = true;
       }
       hipLaunchKernelGGL((conv_kernel<1, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     }
@@ -2521,12 +2595,11 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       const int g = std::min(grid, ns * cp.sets_per_band);
       using GEO = ConvGeom<2, 2>;
       const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<2, 2, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 (train) attribute failed: %s", hipGetErrorString(err));
-        attr_set = true;
       }
       hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
       MST_HIP_CHECK(hipGetLastError());
@@ -2540,12 +2613,11 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       using GEO = ConvGeom<4, 2>;
       static_assert(GEO::WBP == ConvGeom<2, 2>::WBP, "the strip kernel streams conv2's forward weight fragments");
       const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
-      static bool attr_set = false;
-      if (!attr_set) {
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<4, 2, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 strip attribute failed: %s", hipGetErrorString(err));
-        attr_set = true;
       }
       hipLaunchKernelGGL((conv_kernel<4, 2, 3>), dim3(g), dim3(kConvThreads), lds, st, sp);
       MST_HIP_CHECK(hipGetLastError());
@@ -2731,12 +2803,11 @@ int mst_encoder_train_conv2_dgrad(const mst_encoder* e, const float* dy2, int B,
   const int g = std::min(e->num_cus, ns * cp.sets_per_band);
   using GEO = ConvGeom<3, 2>;
   const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+  if (mst::first_use_on_device(attr_set)) {
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<3, 2, 2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 dgrad attribute failed: %s", hipGetErrorString(err));
-    attr_set = true;
   }
   hipLaunchKernelGGL((conv_kernel<3, 2, 2>), dim3(g), dim3(kConvThreads), lds, st, cp);
   MST_HIP_CHECK(hipGetLastError());

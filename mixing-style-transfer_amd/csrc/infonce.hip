@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const float* emb, float* in
 }
 
 __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* emb, const int64_t* labels, const float* inv_norm,
-                                                           float* sim, int N, int D, int row0, float inv_tau, float* out) {
+                                                           float* sim, int N, int D, int row0, float inv_tau, float* rowout) {
   extern __shared__ float srow[];  // [D] normalised anchor
   __shared__ float red[12];
   const int i = row0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,11 +71,26 @@ __global__ __launch_bounds__(256) void infonce_rows_kernel(const float* emb, con
   if (tid == 0) {
     pos = (red[4] + red[5]) + (red[6] + red[7]);
     neg = (red[8] + red[9]) + (red[10] + red[11]);
-    if (pos > 0.f) {
-      atomicAdd(out, -logf(pos / (pos + neg + 1e-8f)));
-      atomicAdd(out + 1, 1.0f);
-    }
+    // per-row result; summed in a fixed order by infonce_reduce_kernel (no float atomics: the loss value is bit-identical
+    // from run to run, as the reference's deterministic mode asks -- src/train.py:30)
+    rowout[2 * blockIdx.x] = pos > 0.f ? -logf(pos / (pos + neg + 1e-8f)) : 0.f;
+    rowout[2 * blockIdx.x + 1] = pos > 0.f ? 1.0f : 0.f;
   }
+}
+
+// out[0] = sum of the per-anchor losses, out[1] = number of anchors with a positive: fixed-shape tree, fixed order
+__global__ __launch_bounds__(256) void infonce_reduce_kernel(const float* rowout, int rows, float* out) {
+  __shared__ float sl[256], sc[256];
+  const int tid = threadIdx.x;
+  float l = 0.f, c = 0.f;
+  for (int r = tid; r < rows; r += 256) l += rowout[2 * r], c += rowout[2 * r + 1];
+  sl[tid] = l, sc[tid] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) sl[tid] += sl[tid + o], sc[tid] += sc[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) out[0] = sl[0], out[1] = sc[0];
 }
 
 // rows kernel of the backward pass: recomputes S_i., then overwrites it with the coefficients c_i.
@@ -169,7 +184,8 @@ extern "C" {
 
 size_t mst_infonce_workspace_bytes(int N, int D) {
   if (N <= 0 || D <= 0) return 0;
-  return mst::align_up((size_t)N * sizeof(float), 256) + mst::align_up((size_t)N * N * sizeof(float), 256);
+  return mst::align_up((size_t)N * sizeof(float), 256) + mst::align_up((size_t)N * N * sizeof(float), 256) +
+         mst::align_up((size_t)2 * N * sizeof(float), 256);
 }
 
 int mst_infonce_forward(const float* emb, const int64_t* labels, int N, int D, int row0, int rows, float temperature,
@@ -183,10 +199,11 @@ int mst_infonce_forward(const float* emb, const int64_t* labels, int N, int D, i
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   float* inv_norm = reinterpret_cast<float*>(workspace);
   float* sim = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + mst::align_up((size_t)N * sizeof(float), 256));
-  MST_HIP_CHECK(hipMemsetAsync(out, 0, 2 * sizeof(float), st));
+  float* rowout = reinterpret_cast<float*>(reinterpret_cast<char*>(sim) + mst::align_up((size_t)N * N * sizeof(float), 256));
   hipLaunchKernelGGL(l2norm_kernel, dim3(N), dim3(256), 0, st, emb, inv_norm, D);
   hipLaunchKernelGGL(infonce_rows_kernel, dim3(rows), dim3(256), (size_t)D * sizeof(float), st, emb, labels, inv_norm, sim,
-                     N, D, row0, 1.0f / temperature, out);
+                     N, D, row0, 1.0f / temperature, rowout);
+  hipLaunchKernelGGL(infonce_reduce_kernel, dim3(1), dim3(256), 0, st, rowout, rows, out);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }

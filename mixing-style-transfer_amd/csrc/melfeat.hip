@@ -18,6 +18,7 @@
 // The sample type is a template parameter (float, or int16 PCM converted in the load).
 #include "common.h"
 #include "fft_wave.h"
+#include "fft_pk.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1016,12 +1017,10 @@ __global__ __launch_bounds__(256) void melfeat_finalize_kernel(const FParams p) 
 
 template <int NFFT, int NB, typename ST>
 hipError_t launch_melfeat(const KParams& kp, int grid, size_t lds, hipStream_t st) {
-  static size_t attr_lds = 0;  // raise the dynamic-LDS limit once per kernel (and again only if it grows)
-  if (lds > attr_lds) {
+  {   // dynamic-LDS limit: a per-device attribute, set on every launch (a cheap driver call)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_kernel<NFFT, NB, ST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_lds = lds;
   }
   hipLaunchKernelGGL((melfeat_kernel<NFFT, NB, ST>), dim3(grid), dim3(kThreads), lds, st, kp);
   return hipGetLastError();
@@ -1029,12 +1028,10 @@ hipError_t launch_melfeat(const KParams& kp, int grid, size_t lds, hipStream_t s
 
 template <int NFFT, typename ST, int WPS>
 hipError_t launch_melfeat_spw(const KParams& kp, int grid, size_t lds, hipStream_t st) {
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(melfeat_spw_kernel<NFFT, ST, WPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_lds = lds;
   }
   hipLaunchKernelGGL((melfeat_spw_kernel<NFFT, ST, WPS>), dim3(grid), dim3(SpwGeom<WPS>::THREADS), lds, st, kp);
   return hipGetLastError();
@@ -1042,6 +1039,8 @@ hipError_t launch_melfeat_spw(const KParams& kp, int grid, size_t lds, hipStream
 
 template <int NFFT>
 constexpr int tw_count_of() { return FftPlan<NFFT / 2>::TW; }
+
+#include "melfeat_v2.inc"
 
 }  // namespace
 
@@ -1060,6 +1059,14 @@ struct mst_plan {
   float2* d_post = nullptr;
   float* d_melw = nullptr;
   LaneBand* d_lanebands = nullptr;
+  // sliding-window kernel (melfeat_v2.inc): packed-FFT twiddles and the segment form of the sparse mel table
+  bool v2_ok = false;
+  int v2_nslot = 0, v2_glen[3] = {0, 0, 0}, v2_goff[3] = {0, 0, 0}, v2_segw_count = 0, v2_wps = 3;
+  float2* d_v2_tw2 = nullptr;
+  float2* d_v2_tw3 = nullptr;
+  float2* d_v2_segw = nullptr;
+  int* d_v2_segstart = nullptr;
+  int* d_v2_segid = nullptr;
 };
 
 namespace {
@@ -1102,6 +1109,79 @@ int runs_per_clip(const mst_plan* p, int B, int F) {
   return (F + fpr - 1) / fpr;
 }
 int pstride_of(const mst_plan* p) { return 4 * p->n_mels + kNumScalars; }
+
+// sliding-window kernel: frames per wave and runs per clip (a run is WPS * fpw frames; like frames_per_run_of, a
+// function of the clip length only, never of the batch size)
+int v2_fpw(const mst_plan* p, int F) { return std::max(1, ((F + 31) / 32 + p->v2_wps - 1) / p->v2_wps); }
+int v2_runs(const mst_plan* p, int F) {
+  const int fpr = p->v2_wps * v2_fpw(p, F);
+  return (F + fpr - 1) / fpr;
+}
+
+// Segment form of the triangular filterbank for melfeat_v2_kernel.  Every bin k feeds at most two ADJACENT bands:
+// the falling edge of band s-1 and the rising edge of band s, where s = seg(k) numbers the interval between two
+// consecutive band centres.  Returns false (kernel not applicable) unless the table has exactly that structure.
+bool v2_build_segments(mst_plan* p, const float* fb, std::vector<float2>& segw, std::vector<int>& segstart,
+                       std::vector<int>& segid) {
+  const int M = p->n_mels, n_bins = p->n_fft / 2 + 1;
+  if (p->n_fft != 1024 || M > 128) return false;
+  std::vector<int> peak(M, -1);
+  for (int m = 0; m < M; ++m) {
+    float best = 0.f;
+    for (int k = 0; k < n_bins; ++k)
+      if (fb[(size_t)k * M + m] > best) best = fb[(size_t)k * M + m], peak[m] = k;
+  }
+  std::vector<int> seg(n_bins, 0);
+  std::vector<float> wl(n_bins, 0.f), wh(n_bins, 0.f);
+  int prev = 0;
+  for (int k = 0; k < n_bins; ++k) {
+    int b0 = -1, b1 = -1, cnt = 0;
+    for (int m = 0; m < M; ++m)
+      if (fb[(size_t)k * M + m] != 0.0f) {
+        if (cnt == 0) b0 = m;
+        b1 = m;
+        ++cnt;
+      }
+    if (cnt > 2 || (cnt == 2 && b1 != b0 + 1)) return false;
+    int s = prev;
+    if (cnt == 2) {
+      s = b1, wl[k] = fb[(size_t)k * M + b0], wh[k] = fb[(size_t)k * M + b1];
+    } else if (cnt == 1) {
+      if (k <= peak[b0]) s = b0, wh[k] = fb[(size_t)k * M + b0];
+      else s = b0 + 1, wl[k] = fb[(size_t)k * M + b0];
+    }
+    if (s < prev) return false;   // segments must be contiguous bin ranges
+    seg[k] = prev = s;
+  }
+  const int nseg = M + 1;
+  std::vector<int> start(nseg, 0), len(nseg, 0);
+  for (int k = n_bins - 1; k >= 0; --k) start[seg[k]] = k, ++len[seg[k]];
+  std::vector<int> order(nseg);
+  for (int i = 0; i < nseg; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
+  p->v2_nslot = (nseg + 63) / 64;
+  if (p->v2_nslot > 3) return false;
+  segstart.assign((size_t)p->v2_nslot * 64, 0);
+  segid.assign((size_t)p->v2_nslot * 64, 134);   // 134: dump slot of the in-scratch exchange arrays
+  int off = 0;
+  for (int r = 0; r < p->v2_nslot; ++r) {
+    int gl = 0;
+    for (int lane = 0; lane < 64 && r * 64 + lane < nseg; ++lane) gl = std::max(gl, len[order[r * 64 + lane]]);
+    if (gl > 16) return false;   // the walk may read 16 zeroed entries past bin 512
+    p->v2_glen[r] = gl, p->v2_goff[r] = off;
+    segw.resize((size_t)(off + gl) * 64, make_float2(0.f, 0.f));
+    for (int lane = 0; lane < 64 && r * 64 + lane < nseg; ++lane) {
+      const int sg = order[r * 64 + lane];
+      segstart[(size_t)r * 64 + lane] = start[sg], segid[(size_t)r * 64 + lane] = sg;
+      for (int i = 0; i < len[sg]; ++i) segw[(size_t)(off + i) * 64 + lane] = make_float2(wl[start[sg] + i], wh[start[sg] + i]);
+    }
+    off += gl;
+  }
+  if (segw.size() & 1) segw.push_back(make_float2(0.f, 0.f));
+  if (segw.empty()) segw.resize(2, make_float2(0.f, 0.f));
+  p->v2_segw_count = (int)segw.size();
+  return true;
+}
 
 }  // namespace
 
@@ -1177,6 +1257,24 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
       const double a = -2.0 * M_PI * (double)k / (double)n_fft;
       post[(size_t)q * 64 + lane] = make_float2((float)cos(a), (float)sin(a));
     }
+  {   // sliding-window kernel tables (standard configuration only)
+    std::vector<float2> segw, t2(mstpk::kTw2Rows * 64), t3(mstpk::kTw3Rows * 64);
+    std::vector<int> segstart, segid;
+    const char* w = getenv("MST_V2_WPS");
+    p->v2_wps = (w && atoi(w) == 2) ? 2 : 3;
+    p->v2_ok = n_fft == 1024 && hop == 256 && v2_build_segments(p, fb, segw, segstart, segid);
+    if (p->v2_ok) {
+      mstpk::fill_twiddles_host(t2.data(), t3.data());
+      int rc2;
+      if ((rc2 = mst::upload(&p->d_v2_tw2, t2.data(), t2.size())) || (rc2 = mst::upload(&p->d_v2_tw3, t3.data(), t3.size())) ||
+          (rc2 = mst::upload(&p->d_v2_segw, segw.data(), segw.size())) ||
+          (rc2 = mst::upload(&p->d_v2_segstart, segstart.data(), segstart.size())) ||
+          (rc2 = mst::upload(&p->d_v2_segid, segid.data(), segid.size()))) {
+        mst_plan_destroy(p);
+        return rc2;
+      }
+    }
+  }
   int rc;
   if ((rc = mst::upload(&p->d_window, window, (size_t)n_fft)) || (rc = mst::upload(&p->d_tw, tw.data(), tw.size())) ||
       (rc = mst::upload(&p->d_tw2, tw2.data(), tw2.size())) ||
@@ -1194,6 +1292,8 @@ void mst_plan_destroy(mst_plan* p) {
   if (!p) return;
   (void)hipFree(p->d_window), (void)hipFree(p->d_tw), (void)hipFree(p->d_tw2), (void)hipFree(p->d_post), (void)hipFree(p->d_melw),
       (void)hipFree(p->d_lanebands);
+  (void)hipFree(p->d_v2_tw2), (void)hipFree(p->d_v2_tw3), (void)hipFree(p->d_v2_segw), (void)hipFree(p->d_v2_segstart),
+      (void)hipFree(p->d_v2_segid);
   delete p;
 }
 
@@ -1203,7 +1303,8 @@ int mst_plan_feature_dim(const mst_plan* p) { return p ? p->feat_dim : MST_EINVA
 size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
   if (!p || B <= 0 || T <= 0) return 0;
   const int F = 1 + T / p->hop;
-  return mst::align_up((size_t)B * runs_per_clip(p, B, F) * pstride_of(p) * sizeof(float), 256);
+  const int runs = std::max(runs_per_clip(p, B, F), p->v2_ok ? v2_runs(p, F) : 0);
+  return mst::align_up((size_t)B * runs * pstride_of(p) * sizeof(float), 256);
 }
 
 }  // extern "C"
@@ -1288,8 +1389,30 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
   const size_t red_need = (size_t)(kWaves * 4 * p->nb * 64 + kWaves * 12) * sizeof(float);
   MST_REQUIRE(red_need <= (size_t)kWaves * nf * (nc + nc / 8) * sizeof(float2), "internal: reduction buffer");
   MST_REQUIRE(lds <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds);
-  const int grid = B * kp.runs_per_clip;
   hipError_t e = hipErrorInvalidValue;
+  // sliding-window kernel for the standard configuration (MST_STAGE_A=spw | generic selects the older kernels)
+  const char* which = getenv("MST_STAGE_A");
+  const bool use_v2 = p->v2_ok && !(which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) && !getenv("MST_MELFEAT_GENERIC");
+  if (use_v2) {
+    K2Params k2{};
+    for (int i = 0; i < 4; ++i) k2.stem[i] = stems4[i];
+    k2.clip_stride = clip_stride, k2.logmel = logmel, k2.partials = reinterpret_cast<float*>(workspace);
+    k2.window = p->d_window, k2.tw2 = p->d_v2_tw2, k2.tw3 = p->d_v2_tw3, k2.segw = p->d_v2_segw;
+    k2.segstart = p->d_v2_segstart, k2.segid = p->d_v2_segid;
+    k2.B = B, k2.T = T, k2.F = F, k2.M = p->n_mels;
+    k2.nslot = p->v2_nslot, k2.segw_count = p->v2_segw_count;
+    for (int r = 0; r < 3; ++r) k2.glen[r] = p->v2_glen[r], k2.goff[r] = p->v2_goff[r];
+    k2.fpw = v2_fpw(p, F), k2.runs_per_clip = v2_runs(p, F), k2.pstride = pstride_of(p);
+    kp.runs_per_clip = k2.runs_per_clip;   // the finalise kernel walks the same records
+    const int wps = p->v2_wps;
+    const size_t lds2 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows) * 64 + p->v2_segw_count + 4 * wps * mstpk::kScr) * sizeof(float2) +
+                        (size_t)(wps * (wps == 2 ? 8 : 4) * 4 * 128 + (wps == 3 ? 1024 : 0)) * sizeof(float);
+    MST_REQUIRE(lds2 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds2);
+    const int grid2 = B * k2.runs_per_clip;
+    if (wps == 3) e = pcm16 ? launch_melfeat_v2<short, 3>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 3>(k2, grid2, lds2, st);
+    else e = pcm16 ? launch_melfeat_v2<short, 2>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 2>(k2, grid2, lds2, st);
+  } else {
+  const int grid = B * kp.runs_per_clip;
   // stem-per-wave-pair kernel for the standard configuration; the generic kernel covers everything else
   // stem-per-wave-pair kernel for the standard configuration; the generic kernel covers everything else
   const int wps = getenv("MST_SPW_WPS") ? atoi(getenv("MST_SPW_WPS")) : 3;
@@ -1321,6 +1444,7 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     MST_CASE(2048)
   }
 #undef MST_CASE
+  }
   }
   if (e != hipSuccess) return mst::fail(MST_EHIP, "melfeat_kernel launch failed: %s", hipGetErrorString(e));
   if (feats) {

@@ -211,7 +211,6 @@ class HipEncoder:
                              "'f16x3-all' (conv1 and conv2) or 'f16' (plain f16 operands, fp32 accumulate: the "
                              "arithmetic of the reference's --use_amp convolutions)")
         self.mode = modes[conv1_precision]
-        self._range_checked = self.mode < 2
         _lib.check(_lib.lib().mst_encoder_set_precision(h, self.mode), "mst_encoder_set_precision")
         self._ws = None
         self.embed_dim = ae.attention_pooling.output_dim
@@ -335,13 +334,6 @@ class HipEncoder:
         """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
         B, _, M, Fr = logmel.shape
         L = _lib.lib()
-        if not self._range_checked:   # conv2's f16 input must stay below 65504: check max(pool1) once (one host sync)
-            self._range_checked = True
-            _, t = self.forward(logmel[:1], feats[:1], taps=True)
-            mx = t["pool1"].abs().max().item()
-            if not mx < 3.0e4:
-                raise _lib.MstError(f"f16 conv2 input: conv1 activations reach {mx:.3g}, too close to the f16 range; use "
-                                    f"conv precision 'f16x3' (conv1 only) or 'fp32'")
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
         if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=logmel.device)

@@ -17,7 +17,7 @@ for d in sorted(glob.glob("$R/gpurun_out/prof_${TAG}_*/")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
-            if "melfeat_spw" in row["Kernel_Name"] or "melfeat_kernel" in row["Kernel_Name"]:
+            if "melfeat_spw" in row["Kernel_Name"] or "melfeat_kernel" in row["Kernel_Name"] or "melfeat_v2" in row["Kernel_Name"]:
                 a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
         for k, (v, n) in acc.items():
             print(f"{k:28s} {v / n:16.0f} per launch ({n} launches)")

@@ -180,6 +180,48 @@ def test_conv_f16x3_split_precision_meets_the_fp32_bar(tag, T, mode):
     assert d_pool < 2e-6 and d_pin < 1e-5 and d_emb < 1e-5
 
 
+@pytest.mark.parametrize("gain", [1.0, 3.0e3, 3.0e5, 1.0e-4])
+def test_conv_f16x3_is_range_safe_for_any_activation_magnitude(gain):
+    """The f16 split-precision modes scale conv2's f16 input per (clip, band) by a power of two derived on the device
+    from a bound on conv1's output -- no host-side range check, nothing refused.  conv1's weights are multiplied by
+    `gain`, which pushes the fp32 pooled activations far beyond the f16 range (gain 3e3: ~2e5 > 65504; 3e5: ~2e7) or
+    down into f16's subnormals (1e-4): the f16x3-all result must stay within 1e-5 of the exact-fp32 kernels, element-wise
+    relative to the tensor's max, and finite."""
+    cfg = cases.CFG_DEFAULT
+    from mst_amd.model import MixingStyleEncoder
+    m = MixingStyleEncoder(channels=8, feature_dim=64, **cfg)
+    sd = cases.make_state_dict(cfg, seed=42)
+    for k in list(sd):
+        if k.endswith("conv1.weight") or k.endswith("conv1.bias"):
+            sd[k] = sd[k] * gain
+        if k.endswith("bn1.running_mean"):   # keep BatchNorm(eval) from cancelling the gain: mean scales, variance does not
+            sd[k] = sd[k] * gain
+    full = dict(m.state_dict())
+    full.update(sd)
+    m.load_state_dict(full, strict=True)
+    m = m.cuda().eval()
+    g = np.load(os.path.join(G, "encoder.npz"))
+    x = torch.stack([cases.synth_clip(c, 66150) for c in (0, 1)], 0)
+    feats = torch.from_numpy(g["default_short.features"]).cuda()
+    with torch.no_grad():
+        lm = m.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        e32, t32 = m.hip_encoder().forward(lm, feats, taps=True)
+        m.conv1_precision = "f16x3-all"
+        e16, t16 = m.hip_encoder().forward(lm, feats, taps=True)
+        m.conv1_precision = "f16"
+        e1 = m.hip_encoder().forward(lm, feats)
+    top = t32["pool1"].abs().max().item()
+    print(f"gain {gain:g}: max fp32 pool1 = {top:.3g} (f16 max 65504)")
+    if gain >= 3e3:
+        assert top > 65504.0
+    assert torch.isfinite(e16).all() and torch.isfinite(e1).all()
+    parity.record(f"f16x3-all vs fp32 kernels, conv1 gain {gain:g}: pool_in", t16["pool_in"], t32["pool_in"])
+    parity.record(f"f16x3-all vs fp32 kernels, conv1 gain {gain:g}: embedding", e16, e32)
+    d_pin = (t16["pool_in"] - t32["pool_in"]).abs().max().item() / t32["pool_in"].abs().max().item()
+    d_emb = (e16 - e32).abs().max().item() / e32.abs().max().item()
+    assert d_pin < 1e-5 and d_emb < 1e-5, (d_pin, d_emb)
+
+
 def test_conv_f16_amp_mode_matches_its_own_definition():
     """Opt-in "f16" mode (1-term f16 MFMA = the reference's --use_amp conv arithmetic): conv inputs and weights are
     rounded to float16, everything else is fp32.  Checked at 1e-4 against the oracle evaluated with exactly those

@@ -255,9 +255,11 @@ def test_device_stager_overlapped_h2d():
 
 @pytest.mark.parametrize("T", [1024, 4096 + 256 * 3, 256 * 33, 256 * 55 + 128, 256 * 97 + 4, 256 * 1024 + 252])
 def test_two_stage_a_kernels_agree_on_ragged_run_partitions(T):
-    """The stem-per-wave-pair kernel and the generic kernel share only the FFT helper; their frame / run / batch
-    bookkeeping is independent.  Lengths chosen so that the number of frames is not a multiple of the 16-frame batch,
-    of the run length, or of the hop (last partial frame), incl. one clip shorter than a run."""
+    """The default stage-A kernel (sliding window, packed radix-16x8x8 FFT, segment mel) and the generic kernel (radix
+    8x8x4x4 FFT, per-band gather) share no arithmetic and no frame / run / block bookkeeping.  Lengths chosen so that the
+    number of frames is not a multiple of the block, of the run length, or of the hop (last partial frame), incl. one
+    clip shorter than a run.  Kernel vs kernel: the 1e-4 log-mel bound (two different fp32 FFT factorisations differ by
+    their rounding noise); both against the oracle with the noise-unit criterion of check_logmel."""
     x = torch.stack([cases.synth_clip(c, T) for c in (3, 8, 9)], 0)
     ext = fe()
     os.environ.pop("MST_MELFEAT_GENERIC", None)
@@ -267,7 +269,7 @@ def test_two_stage_a_kernels_agree_on_ragged_run_partitions(T):
         f_gen, lm_gen = run(x, ext)
     finally:
         os.environ.pop("MST_MELFEAT_GENERIC", None)
-    assert scaled_err(lm_spw, lm_gen) <= 2e-5
+    assert scaled_err(lm_spw, lm_gen) <= 1e-4
     check_feats(f_spw, f_gen.numpy())
     rf, rmel = ofeat.extract_all_features(x, return_mel=True)
     check_logmel(lm_spw, torch.log(rmel + 1e-10), x=x)
