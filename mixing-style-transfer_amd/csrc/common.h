@@ -59,6 +59,25 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// Order-independent ("deterministic") accumulation for cross-workgroup reductions.  Floating-point atomics make a sum
+// depend on the order in which workgroups happen to arrive; integer atomics do not.  A value x is split exactly into
+// its integer part and its fraction scaled by 2^48, and both go into 64-bit integer accumulators: the total is the
+// same bit pattern whatever the arrival order (the reference asks for deterministic training, src/train.py:30).
+// Range |x| < 2^62; resolution 2^-48 absolute (3.6e-15) -- far below fp32 / the double partial sums it replaces;
+// up to 2^14 contributions per accumulator without overflow of the fraction word.
+struct DetAcc {
+  long long hi, lo;
+};
+__device__ __forceinline__ void det_add(DetAcc* a, double x) {
+  const double hi = rint(x);
+  const double lo = rint((x - hi) * 281474976710656.0);   // 2^48; |x - hi| <= 0.5
+  atomicAdd(reinterpret_cast<unsigned long long*>(&a->hi), (unsigned long long)(long long)hi);
+  atomicAdd(reinterpret_cast<unsigned long long*>(&a->lo), (unsigned long long)(long long)lo);
+}
+__device__ __forceinline__ double det_get(const DetAcc& a) {
+  return (double)a.hi + (double)a.lo * (1.0 / 281474976710656.0);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -172,7 +172,7 @@ struct ConvParams {
   // how a later weight-gradient MFMA wants its A operand; per-(band, channel) sums of y and y^2 over the valid
   // positions go to stats[band][COUT][2] (double) for the batch statistics of train-mode BatchNorm.
   float* yraw;
-  double* stats;
+  mst::DetAcc* stats;      // order-independent accumulators (common.h): [nsub][COUT][2]
   const float* bias;          // [nsub][COUT]
   int raw_rows, raw_cols;     // valid extent of the convolution output plane
   // MODE 2 (conv2 input gradient): raw output to out[clip][band][COUT][raw_rows][raw_cols], times the Dropout keep-mask
@@ -184,11 +184,12 @@ struct ConvParams {
   // split-precision f16 path: per-(clip, band) power-of-two scale of conv1's pooled output, [B][nsub][2] = (s, 1/s)
   // (f16_scale_kernel); conv1 stores m * s as f16 hi/lo, conv2 folds 1/s into its affine.  NULL = unscaled.
   const float* f16_scale;
+  const float* f16_winv;      // [nsub][COUT] inverse of the weight fragments' per-channel pre-scale
 };
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
 template <int NT, int COUT>
-__device__ __forceinline__ void flush_stats(double (&st)[NT][2], double* stats, int band, int lane) {
+__device__ __forceinline__ void flush_stats(double (&st)[NT][2], mst::DetAcc* stats, int band, int lane) {
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -196,7 +197,7 @@ __device__ __forceinline__ void flush_stats(double (&st)[NT][2], double* stats, 
       double x = st[n][k];
       x += __shfl_xor(x, 16, 64);
       x += __shfl_xor(x, 32, 64);
-      if (lane < 16) atomicAdd(&stats[((size_t)band * COUT + n * 16 + lane) * 2 + k], x);
+      if (lane < 16) mst::det_add(&stats[((size_t)band * COUT + n * 16 + lane) * 2 + k], x);
       st[n][k] = 0.0;
     }
 }
@@ -759,7 +760,15 @@ __global__ __launch_bounds__(64) void f16_scale_kernel(const float2* __restrict_
 }
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-constexpr float kF16Scale = 1024.0f;  // weight pre-scale (folded back in the epilogue)
+// weight pre-scale of the f16 fragments: an exact power of two per (band, output channel), chosen on the host so that the
+// filter's largest |w| lands in [2^13, 2^14) -- wl = w - wh stays a normal f16 whatever the weights' magnitude -- and
+// folded back per channel in the epilogue (ConvParams::f16_winv)
+__host__ inline int f16_weight_exponent(float maxabs) {
+  if (!(maxabs > 0.f) || !(maxabs < INFINITY)) return 10;
+  int ex;
+  (void)frexpf(maxabs, &ex);   // maxabs in [2^(ex-1), 2^ex)
+  return std::max(-100, std::min(100, 14 - ex));
+}
 constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
 
 // TERMS = 3: split precision (fp32-equivalent, see above).  TERMS = 1: plain f16 operands (`x ~ xh`, `w ~ wh`), fp32
@@ -933,7 +942,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
       for (int n = 0; n < NT; ++n) {
         const int ch = n * 16 + j;
         float2 ac = aff[ch];
-        ac.x *= (1.0f / kF16Scale);  // undo the weight pre-scale
+        ac.x *= p.f16_winv[cur.band * C::COUT + ch];  // undo the weight pre-scale
 #pragma unroll
         for (int wv = 0; wv < C::WPG; ++wv) {
           float m = 0.f;
@@ -1090,12 +1099,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     if (chunk == NCH - 1 && cur.valid) {
       const int j = lane & 15, g = lane >> 4;
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * 64;
-      const float inv_s = (1.0f / kF16Scale) * (p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2 + 1] : 1.0f);
+      const float inv_s = p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2 + 1] : 1.0f;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const int ch = n * 16 + j;
         float2 ac = aff[ch];
-        ac.x *= inv_s;   // undo the weight pre-scale and the input's range scale (both exact powers of two)
+        ac.x *= inv_s * p.f16_winv[cur.band * 64 + ch];   // undo the input's range scale and the weight pre-scale (exact powers of two)
         float m = 0.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
@@ -1302,6 +1311,7 @@ struct mst_encoder {
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
   void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
   float* w1norm = nullptr;    // [nsub][32] L1 norm of every conv1 filter (range bound of the f16 path)
+  float *f16_winv1 = nullptr, *f16_winv2 = nullptr;   // [nsub][32], [nsub][64]: inverse pre-scale of the f16 weight fragments
   int conv1_f16x3 = 0;        // 0 exact fp32, 1 conv1 f16x3, 2 conv1 + conv2 f16x3, 3 conv1 + conv2 plain f16 (amp)
   // un-folded parameters for the training forward (batch-statistics BatchNorm)
   float *c1b = nullptr, *bn1w = nullptr, *bn1b = nullptr, *c2b = nullptr, *bn2w = nullptr, *bn2b = nullptr;
@@ -1374,7 +1384,7 @@ std::vector<float> conv_fragments(const float* w, int nsub, int cout, int cin, i
 // yraw is kept: the backward pass recomputes everything between y and the pooled output from it.
 // ------------------------------------------------------------------------------------------
 struct FoldParams {
-  const double* stats;     // [nsub][COUT][2]
+  const mst::DetAcc* stats;   // [nsub][COUT][2]
   const float *bn_w, *bn_b;  // [nsub][COUT]
   const float* film;       // [B][nsub*192]
   float2* aff;             // [B][nsub][COUT]
@@ -1387,8 +1397,8 @@ struct FoldParams {
 __global__ void bn_fold_kernel(const FoldParams p) {   // grid (nsub, B), block COUT
   const int band = blockIdx.x, b = blockIdx.y, ch = threadIdx.x;
   const size_t i = (size_t)band * p.cout + ch;
-  const double mean = p.stats[i * 2] / p.count;
-  const double var = fmax(p.stats[i * 2 + 1] / p.count - mean * mean, 0.0);
+  const double mean = mst::det_get(p.stats[i * 2]) / p.count;
+  const double var = fmax(mst::det_get(p.stats[i * 2 + 1]) / p.count - mean * mean, 0.0);
   const double invstd = 1.0 / sqrt(var + (double)p.eps);
   if (b == 0) p.bnstat[i] = make_float2((float)mean, (float)invstd);
   const float* fl = p.film + ((size_t)b * p.nsub + band) * 192;
@@ -1478,8 +1488,9 @@ struct ApplyBwdParams {
   const float* dpool;      // upstream gradient of the pooled activation
   long long dp_clip, dp_band, dp_ch;   // its strides (floats); rows are dp_cols apart
   int dp_rows, dp_cols;
-  float* dfilm;            // [B][nsub*192]  (+=)
-  double* sums;            // [nsub][COUT][2] (+=)  S1, S2
+  float* dfilm;            // [B][nsub*192]  (+=, by dfilm_finish_kernel from dfilm_acc)
+  mst::DetAcc* dfilm_acc;  // [B][nsub*192] order-independent accumulators of this call (zeroed per call)
+  mst::DetAcc* sums;       // [nsub][COUT][2] (+=)  S1, S2
   float* dy;               // pass B: NCHW per band, or NULL: in place over yraw in accumulator order (dy_acc)
   float* dy_acc;
   int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
@@ -1573,11 +1584,11 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
   s1 += __shfl_xor(s1, 16, 64), s1 += __shfl_xor(s1, 32, 64);
   s2 += __shfl_xor(s2, 16, 64), s2 += __shfl_xor(s2, 32, 64);
   if (lane < 16 && w0 + wave < w1) {
-    float* fl = p.dfilm + ((size_t)clip * p.nsub + band) * 192;
-    atomicAdd(fl + p.goff + ch, dgam);
-    atomicAdd(fl + p.boff + ch, dbet);
-    atomicAdd(p.sums + ((size_t)band * C::COUT + ch) * 2, s1);
-    atomicAdd(p.sums + ((size_t)band * C::COUT + ch) * 2 + 1, s2);
+    mst::DetAcc* fl = p.dfilm_acc + ((size_t)clip * p.nsub + band) * 192;
+    mst::det_add(fl + p.goff + ch, (double)dgam);
+    mst::det_add(fl + p.boff + ch, (double)dbet);
+    mst::det_add(p.sums + ((size_t)band * C::COUT + ch) * 2, s1);
+    mst::det_add(p.sums + ((size_t)band * C::COUT + ch) * 2 + 1, s2);
   }
 }
 
@@ -1599,7 +1610,8 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
   const float2 ms = p.bnstat[band * C::COUT + ch];
   const float gb = p.bn_w[band * C::COUT + ch];
   const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
-  const double m1 = p.sums[((size_t)band * C::COUT + ch) * 2] / p.count, m2 = p.sums[((size_t)band * C::COUT + ch) * 2 + 1] / p.count;
+  const double m1 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2]) / p.count,
+               m2 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2 + 1]) / p.count;
   const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (size_t)u * NV);
   float v[NV], df[NV];
 #pragma unroll
@@ -1652,7 +1664,7 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
 struct WgradParams {
   const float* x;          // logmel [B][8][n_mels][frames]
   const float* dy;         // accumulator order [B][nsub][tr][tc][2][64][20]
-  float* dw;               // [nsub][32][8][49]  (+=, zeroed by the caller)
+  mst::DetAcc* dw;         // [nsub][32][8][49] order-independent accumulators (+=, zeroed by the caller; det_to_float_kernel)
   int B, nsub, tiles_r, tiles_c;
   int in_rows, in_cols, in_cstride, in_bandoff;
   long long in_clipstride;
@@ -1783,7 +1795,7 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * c + 4 * g + r;
-            atomicAdd(p.dw + ((size_t)band * 32 + co) * 392 + nidx, acc[c][k][r]);
+            mst::det_add(p.dw + ((size_t)band * 32 + co) * 392 + nidx, (double)acc[c][k][r]);
             acc[c][k][r] = 0.f;
           }
       }
@@ -1993,7 +2005,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int co = 16 * c + 4 * g + r;
-            atomicAdd(p.dw + ((size_t)band * 64 + co) * 1568 + chunk * 392 + nidx, acc[c][k][r]);
+            mst::det_add(p.dw + ((size_t)band * 64 + co) * 1568 + chunk * 392 + nidx, (double)acc[c][k][r]);
             acc[c][k][r] = 0.f;
           }
       }
@@ -2093,9 +2105,24 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   flush(cur_band, cur_chunk);
 }
 
-__global__ void sums_to_dbn_kernel(const double* sums, float* dbn, int n) {
+__global__ void sums_to_dbn_kernel(const mst::DetAcc* sums, float* dbn, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dbn[2 * i] = (float)sums[2 * i + 1], dbn[2 * i + 1] = (float)sums[2 * i];
+  if (i < n) dbn[2 * i] = (float)mst::det_get(sums[2 * i + 1]), dbn[2 * i + 1] = (float)mst::det_get(sums[2 * i]);
+}
+
+// dfilm[clip][band][goff + ch] += gamma gradient, [boff + ch] += beta gradient of this layer (single writer per element)
+__global__ void dfilm_finish_kernel(const mst::DetAcc* acc, float* dfilm, int n192, int goff, int boff, int cout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B * nsub * 2 * cout
+  if (i >= n192 / 192 * 2 * cout) return;
+  const int cb = i / (2 * cout), r = i % (2 * cout);
+  const int slot = r < cout ? goff + r : boff + (r - cout);
+  dfilm[(size_t)cb * 192 + slot] += (float)mst::det_get(acc[(size_t)cb * 192 + slot]);
+}
+
+// float result of an order-independent accumulator array (weight gradients)
+__global__ void det_to_float_kernel(const mst::DetAcc* acc, float* out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)mst::det_get(acc[i]);
 }
 
 // conv weights [nsub][COUT][CIN][49] (device) -> MFMA B-fragment chunks, same layout as conv_fragments() builds on the host
@@ -2205,7 +2232,24 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
       for (int lane = 0; lane < 64; ++lane)
         af[((size_t)s * (A / 16) + n) * 64 + lane] = w->att0_w[(size_t)(n * 16 + (lane & 15)) * C + 4 * s + (lane >> 4)];
   e->att2_b = w->att2_b[0];
-  // conv1 weights, f16 hi/lo split of (2^10 * w): [band][step][nt][hi/lo][lane][8 channels]
+  // per-(band, output channel) power-of-two pre-scale of the f16 weight fragments, and its inverse for the epilogues
+  std::vector<int> wex1((size_t)ns * 32), wex2((size_t)ns * 64);
+  std::vector<float> winv1((size_t)ns * 32), winv2((size_t)ns * 64);
+  for (int b = 0; b < ns; ++b) {
+    for (int co = 0; co < 32; ++co) {
+      float mx = 0.f;
+      for (int i = 0; i < 392; ++i) mx = std::max(mx, fabsf(w->conv1_w[((size_t)b * 32 + co) * 392 + i]));
+      wex1[(size_t)b * 32 + co] = f16_weight_exponent(mx);
+      winv1[(size_t)b * 32 + co] = ldexpf(1.0f, -wex1[(size_t)b * 32 + co]);
+    }
+    for (int co = 0; co < 64; ++co) {
+      float mx = 0.f;
+      for (int i = 0; i < 1568; ++i) mx = std::max(mx, fabsf(w->conv2_w[((size_t)b * 64 + co) * 1568 + i]));
+      wex2[(size_t)b * 64 + co] = f16_weight_exponent(mx);
+      winv2[(size_t)b * 64 + co] = ldexpf(1.0f, -wex2[(size_t)b * 64 + co]);
+    }
+  }
+  // conv1 weights, f16 hi/lo split of (2^e * w): [band][step][nt][hi/lo][lane][8 channels]
   std::vector<_Float16> f16((size_t)ns * kF16Steps * 2 * 2 * 64 * 8);
   for (int b = 0; b < ns; ++b)
     for (int st = 0; st < kF16Steps; ++st)
@@ -2213,7 +2257,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 8; ++j) {
             const int tap = 4 * st + (lane >> 4), co = n * 16 + (lane & 15);
-            const float wv = tap < 49 ? kF16Scale * w->conv1_w[(((size_t)b * 32 + co) * 8 + j) * 49 + tap] : 0.f;
+            const float wv = tap < 49 ? ldexpf(w->conv1_w[(((size_t)b * 32 + co) * 8 + j) * 49 + tap], wex1[(size_t)b * 32 + co]) : 0.f;
             const _Float16 h = (_Float16)wv;
             const size_t base = ((((size_t)b * kF16Steps + st) * 2 + n) * 2) * 64 * 8;
             f16[base + (size_t)lane * 8 + j] = h;
@@ -2227,7 +2271,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
           for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
               const int tap = 4 * st + (lane >> 4), co = n * 16 + (lane & 15), ci = ck * 8 + j;
-              const float wv = tap < 49 ? kF16Scale * w->conv2_w[(((size_t)b * 64 + co) * 32 + ci) * 49 + tap] : 0.f;
+              const float wv = tap < 49 ? ldexpf(w->conv2_w[(((size_t)b * 64 + co) * 32 + ci) * 49 + tap], wex2[(size_t)b * 64 + co]) : 0.f;
               const _Float16 h = (_Float16)wv;
               const size_t base = (((((size_t)b * 4 + ck) * kF16Steps + st) * 4 + n) * 2) * 64 * 8;
               g16[base + (size_t)lane * 8 + j] = h;
@@ -2249,7 +2293,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   }
 #define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
 #define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
-  UP(w1norm, w1n);
+  UP(w1norm, w1n); UP(f16_winv1, winv1); UP(f16_winv2, winv2);
   UP(w1frag, f1); UP(w2frag, f2); UP(s1, s1); UP(t1, t1); UP(s2, s2); UP(t2, t2);
   UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projfrag, pfrag); UP(att0frag, af);
   UPP(b0, w->mlp0_b, H); UPP(b3, w->mlp3_b, H); UPP(hb, w->head_b, ns * 192);
@@ -2285,7 +2329,7 @@ void mst_encoder_destroy(mst_encoder* e) {
                    e->bn2w, e->bn2b, e->w2dfrag};
   for (float* q : ptrs) (void)hipFree(q);
   (void)hipFree(e->w1frag16);
-  (void)hipFree(e->w1norm);
+  (void)hipFree(e->w1norm), (void)hipFree(e->f16_winv1), (void)hipFree(e->f16_winv2);
   (void)hipFree(e->w2frag16);
   delete e;
 }
@@ -2361,6 +2405,7 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
       }
       const bool both = e->conv1_f16x3 >= 2;
+      cp.f16_winv = e->f16_winv1;
       if (both && !(taps && taps->pool1)) cp.out = nullptr;   // fp32 pool1 only when a tap asks for it
       if (both) {   // range scale of conv2's f16 input from a rigorous bound (see f16_scale_kernel): no host check, no refusal
         unsigned* xmax = reinterpret_cast<unsigned*>(ws + L.xmax);
@@ -2419,6 +2464,7 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 f16x3 attribute failed: %s", hipGetErrorString(err));
       }
       cp.f16_scale = reinterpret_cast<const float*>(ws + L.f16scale);
+      cp.f16_winv = e->f16_winv2;
       const h16x8* ih = reinterpret_cast<const h16x8*>(ws + L.pool1_h16);
       const h16x8* il = reinterpret_cast<const h16x8*>(ws + L.pool1_l16);
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w2frag16);
@@ -2461,7 +2507,7 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
 namespace {
 struct TrainLayout {
   WsLayout base;
-  size_t y1, y2, stats1, stats2, bn1, bn2, total;
+  size_t y1, y2, stats1, stats2, bn1, bn2, dfilm_acc, dw_acc, total;
   int tr1, tc1, tr2, tc2;
 };
 TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
@@ -2479,10 +2525,12 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   };
   T.y1 = take((size_t)B * ns * T.tr1 * T.tc1 * 2 * 64 * 20 * 4);
   T.y2 = take((size_t)B * ns * T.tr2 * T.tc2 * 4 * 64 * 16 * 4);
-  T.stats1 = take((size_t)ns * 32 * 2 * 8);
-  T.stats2 = take((size_t)ns * 64 * 2 * 8);
+  T.stats1 = take((size_t)ns * 32 * 2 * sizeof(mst::DetAcc));
+  T.stats2 = take((size_t)ns * 64 * 2 * sizeof(mst::DetAcc));
   T.bn1 = take((size_t)ns * 32 * 8);
   T.bn2 = take((size_t)ns * 64 * 8);
+  T.dfilm_acc = take((size_t)B * ns * 192 * sizeof(mst::DetAcc));
+  T.dw_acc = take((size_t)ns * 64 * 1568 * sizeof(mst::DetAcc));   // weight-gradient accumulators (conv2's size; conv1 reuses it)
   T.total = o;
   return T;
 }
@@ -2513,10 +2561,10 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   float* scores = reinterpret_cast<float*>(ws + L.scores);
   float* y1 = reinterpret_cast<float*>(ws + T.y1);
   float* y2 = reinterpret_cast<float*>(ws + T.y2);
-  double* stats1 = reinterpret_cast<double*>(ws + T.stats1);
-  double* stats2 = reinterpret_cast<double*>(ws + T.stats2);
-  MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * 8, st));
-  MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * 8, st));
+  mst::DetAcc* stats1 = reinterpret_cast<mst::DetAcc*>(ws + T.stats1);
+  mst::DetAcc* stats2 = reinterpret_cast<mst::DetAcc*>(ws + T.stats2);
+  MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * sizeof(mst::DetAcc), st));
+  MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * sizeof(mst::DetAcc), st));
   if (taps && taps->film_in) {   // FiLM parameters computed by the caller (its MLP keeps its autograd graph)
     MST_HIP_CHECK(hipMemcpyAsync(film, taps->film_in, (size_t)B * ns * 192 * 4, hipMemcpyDeviceToDevice, st));
   } else {   // FiLM MLP (its eval-mode affines are overwritten by bn_fold_kernel below)
@@ -2672,9 +2720,11 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   p.dpool = dpool, p.dp_clip = dp_clip, p.dp_band = dp_band, p.dp_ch = dp_ch;
   p.dfilm = dfilm, p.dy = dy, p.B = B, p.nsub = ns;
   const int cout = layer == 1 ? 32 : 64;
-  double* sums = reinterpret_cast<double*>(ws + (layer == 1 ? T.stats1 : T.stats2));   // forward sums are spent: reuse
+  mst::DetAcc* sums = reinterpret_cast<mst::DetAcc*>(ws + (layer == 1 ? T.stats1 : T.stats2));   // forward sums are spent: reuse
   p.sums = sums;
-  MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * 8, st));
+  MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * sizeof(mst::DetAcc), st));
+  p.dfilm_acc = reinterpret_cast<mst::DetAcc*>(ws + T.dfilm_acc);
+  MST_HIP_CHECK(hipMemsetAsync(p.dfilm_acc, 0, (size_t)B * ns * 192 * sizeof(mst::DetAcc), st));
   if (layer == 1) {
     p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
     p.dy_acc = dy ? nullptr : reinterpret_cast<float*>(ws + T.y1);
@@ -2708,6 +2758,8 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   MST_HIP_CHECK(hipGetLastError());
   // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
   hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout);
+  hipLaunchKernelGGL(dfilm_finish_kernel, dim3((B * ns * 2 * cout + 255) / 256), dim3(256), 0, st, p.dfilm_acc, dfilm,
+                     B * ns * 192, p.goff, p.boff, cout);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
@@ -2747,8 +2799,10 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
   const int ns = e->cfg.n_subbands;
-  MST_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ns * 32 * 392 * 4, st));
-  WgradParams wp{logmel, reinterpret_cast<const float*>(ws + T.y1), dw, B, ns, T.tr1, T.tc1,
+  mst::DetAcc* dwa = reinterpret_cast<mst::DetAcc*>(ws + T.dw_acc);
+  const long long ndw = (long long)ns * 32 * 392;
+  MST_HIP_CHECK(hipMemsetAsync(dwa, 0, (size_t)ndw * sizeof(mst::DetAcc), st));
+  WgradParams wp{logmel, reinterpret_cast<const float*>(ws + T.y1), dwa, B, ns, T.tr1, T.tc1,
                  e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
                  (long long)8 * e->cfg.n_mels * frames, 0};
   const long long total = (long long)ns * B * T.tr1 * T.tc1;
@@ -2756,6 +2810,7 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
   const int g8 = (int)std::min<long long>(e->num_cus, total);
   if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
+  hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
@@ -2771,14 +2826,17 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char* ws = reinterpret_cast<char*>(workspace);
   const int ns = e->cfg.n_subbands;
-  MST_HIP_CHECK(hipMemsetAsync(dw, 0, (size_t)ns * 64 * 1568 * 4, st));
-  WgradParams wp{pool1, reinterpret_cast<const float*>(ws + T.y2), dw, B, ns, T.tr2, T.tc2,
+  mst::DetAcc* dwa = reinterpret_cast<mst::DetAcc*>(ws + T.dw_acc);
+  const long long ndw = (long long)ns * 64 * 1568;
+  MST_HIP_CHECK(hipMemsetAsync(dwa, 0, (size_t)ndw * sizeof(mst::DetAcc), st));
+  WgradParams wp{pool1, reinterpret_cast<const float*>(ws + T.y2), dwa, B, ns, T.tr2, T.tc2,
                  e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1,
                  getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0};
   const long long total = (long long)ns * B * T.tr2 * T.tc2;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
   const int g = (int)std::min<long long>(e->num_cus & ~3, 4 * total);   // groups of 4 workgroups (one per input-channel chunk)
   hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
+  hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }

@@ -116,7 +116,14 @@ constexpr int kTw3Rows = 14;      // pass-3 twiddle rows of 64: [u][t-1][lane]
 __device__ __forceinline__ int jb_of(int lane) { return lane ? 128 - lane : 64; }
 
 // In: x[t] = element lane + 64 t.  Out: x[t] = X[lane + 128 t], x[8 + t] = X[jb + 128 t], jb = jb_of(lane).
-__device__ __forceinline__ void fft1024(v2f (&x)[16], v2f* scr, const v2f* tw2, const v2f* tw3, int lane) {
+// fill1 / fill2: independent work of the caller, placed right after the reads of exchange 1 / 2 have been issued --
+// it executes while the wave would otherwise sit in the LDS round trip.
+struct NoFill {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <class F1 = NoFill, class F2 = NoFill>
+__device__ __forceinline__ void fft1024(v2f (&x)[16], v2f* scr, const v2f* tw2, const v2f* tw3, int lane, F1 fill1 = F1(),
+                                        F2 fill2 = F2()) {
   dft16(x);
   {
     v4f* row = reinterpret_cast<v4f*>(scr + 18 * lane);
@@ -135,11 +142,14 @@ __device__ __forceinline__ void fft1024(v2f (&x)[16], v2f* scr, const v2f* tw2, 
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int t = 0; t < 8; ++t) x[8 * u + t] = src[72 * u + 144 * t];
+    v2f w2[8];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) w2[t] = tw2[(t - 1) * 64 + lane];
+    fill1();
 #pragma unroll
     for (int t = 1; t < 8; ++t) {
-      const v2f w = tw2[(t - 1) * 64 + lane];
-      x[t] = cmul(x[t], w);
-      x[8 + t] = cmul(x[8 + t], w);
+      x[t] = cmul(x[t], w2[t]);
+      x[8 + t] = cmul(x[8 + t], w2[t]);
     }
     dft8(x);
     dft8(x + 8);
@@ -158,6 +168,7 @@ __device__ __forceinline__ void fft1024(v2f (&x)[16], v2f* scr, const v2f* tw2, 
     const v2f* sb = scr + jb_of(lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) x[t] = sa[144 * t], x[8 + t] = sb[144 * t];
+    fill2();
 #pragma unroll
     for (int t = 1; t < 8; ++t) {
       x[t] = cmul(x[t], tw3[(t - 1) * 64 + lane]);

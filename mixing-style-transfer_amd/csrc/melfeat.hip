@@ -90,9 +90,13 @@ __device__ __forceinline__ float2 shfl2(float2 a, int src) {
 
 // Sample type of the waveform in HBM: fp32, or int16 PCM (the ingest format: half the PCIe / HBM bytes; converted
 // with the exact scale 2^-15, so the result equals the fp32 path run on float(pcm) / 32768 bit for bit).
+#ifndef MST_V2_NT
+#define MST_V2_NT 0   // experiment switch: bit 0 streaming (non-temporal) sample loads, bit 1 non-temporal log-mel stores
+#endif
 template <typename ST> struct Smp;
 template <> struct Smp<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ float lds(const float* p) { return (MST_V2_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
   static __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
   static __device__ __forceinline__ void ld4(const float* p, float (&x)[4]) {
     const float4 q = *reinterpret_cast<const float4*>(p);
@@ -102,6 +106,9 @@ template <> struct Smp<float> {
 template <> struct Smp<short> {
   static constexpr float kScale = 1.0f / 32768.0f;
   static __device__ __forceinline__ float ld(const short* p) { return (float)*p * kScale; }
+  static __device__ __forceinline__ float lds(const short* p) {
+    return (float)((MST_V2_NT & 1) ? __builtin_nontemporal_load(p) : *p) * kScale;
+  }
   static __device__ __forceinline__ float2 ld2(const short* p) {
     const short2 q = *reinterpret_cast<const short2*>(p);
     return make_float2((float)q.x * kScale, (float)q.y * kScale);

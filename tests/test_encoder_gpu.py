@@ -378,11 +378,20 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgnam
         d_t32 = (pb.grad.double() - pc.grad).abs().max().item() / den
         worst_hip, worst_t32 = max(worst_hip, d_hip), max(worst_t32, d_t32)
         errs.append((n, d_hip, d_t32))
+    # the one known fp32-conditioning outlier, by name: sum_p dy[p] x[p] over ~10^5 positions with x ~ -23 (silence floor of
+    # the lowest sub-band) against sum_p dy[p] = 0 (batch-statistics BatchNorm removes the mean) -- the products cancel to
+    # ~1e-3 of their magnitude, so fp32 accumulation carries ~1e-3 relative error in ANY order of summation
+    KNOWN = {"default": {"audio_encoder.subnet_cnns.0.conv1.weight": 5e-3}, "baseline_sh": {}}[cfgname]
     out_hip = [(n, f"{a:.1e}") for n, a, _ in errs if a >= 1e-4]
     out_t32 = [(n, f"{b:.1e}") for n, _, b in errs if b >= 1e-4]
     print(f"{cfgname}: parameter-gradient error vs float64 autograd over {len(errs)} tensors: hip trunk worst {worst_hip:.2e}, "
           f"outliers {out_hip}; PyTorch fp32 worst {worst_t32:.2e}, {len(out_t32)} outliers")
-    assert worst_hip < 5e-2 and len(out_hip) <= 0.05 * len(errs) and len(out_hip) <= len(out_t32) + 3, out_hip
+    hip_errs = np.array([a for _, a, _ in errs])
+    parity.note(f"train gradients vs float64 autograd [{cfgname}], norm-wise per tensor", tensors=len(errs),
+                hip_max=float(hip_errs.max()), hip_p90=float(np.percentile(hip_errs, 90)), hip_median=float(np.median(hip_errs)),
+                hip_beyond_1e4=len(out_hip), torch_fp32_max=worst_t32, torch_fp32_beyond_1e4=len(out_t32))
+    for n, a, _ in errs:
+        assert a < KNOWN.get(n, 1e-4), (n, a, out_hip)
     for (n, ba), (_, bc) in zip(model.named_buffers(), ref64.named_buffers()):
         if "running" in n:
             close(ba.cpu(), bc.cpu(), 1e-4)
@@ -533,3 +542,34 @@ def test_embedding_cache_matches_the_reference_loop_fixture(tmp_path):
     err = ((got - rf).abs() / (rf.abs() + 2.0)).max().item()
     print(f"dataset features vs reference fixture: scaled err {err:.2e}")
     assert err < 1e-4
+
+
+def test_training_step_is_bit_deterministic():
+    """The reference trainer asks for deterministic behaviour (src/train.py:22-31).  Every cross-workgroup reduction of the
+    training path -- batch statistics, FiLM / BatchNorm gradient sums, both convolution weight gradients, the InfoNCE
+    loss -- accumulates through order-independent integer accumulators (csrc/common.h DetAcc) or a fixed-order tree:
+    two identical steps from the same state and seed give bit-identical loss and gradients."""
+    import copy
+    from mst_amd.loss import InfoNCELoss
+    cfg = cases.CFG_DEFAULT
+    base, _ = build_model(cfg)
+    B, T = 6, 44100
+    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0).cuda()
+    stems = omel.tensor_to_stems_dict(x)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(B, 64, generator=g).cuda()
+    labels = (torch.arange(B) // 2).cuda()
+    runs = []
+    for _ in range(2):
+        m = copy.deepcopy(base).train()
+        m.train_backend = "hip-strict"
+        torch.manual_seed(1234)                       # Dropout masks
+        loss = InfoNCELoss(0.1)(m(stems, feats), labels)
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                     {n: b.detach().clone() for n, b in m.named_buffers() if "running" in n}))
+    (l0, g0, s0), (l1, g1, s1) = runs
+    assert torch.equal(l0, l1), (l0.item(), l1.item())
+    diff = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+    assert not diff, f"{len(diff)} gradient tensors differ between two identical steps, e.g. {diff[:3]}"
+    assert all(torch.equal(s0[n], s1[n]) for n in s0)
