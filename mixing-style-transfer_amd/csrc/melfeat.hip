@@ -1413,7 +1413,7 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     kp.runs_per_clip = k2.runs_per_clip;   // the finalise kernel walks the same records
     const int wps = p->v2_wps;
     const size_t lds2 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows) * 64 + p->v2_segw_count + 4 * wps * mstpk::kScr) * sizeof(float2) +
-                        (size_t)(wps * (wps == 2 ? 8 : 4) * 4 * 128 + (wps == 3 ? 1024 : 0)) * sizeof(float);
+                        (size_t)(wps * (wps == 2 ? 8 : 4) * 4 * 128 + 1024) * sizeof(float);
     MST_REQUIRE(lds2 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds2);
     const int grid2 = B * k2.runs_per_clip;
     if (wps == 3) e = pcm16 ? launch_melfeat_v2<short, 3>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 3>(k2, grid2, lds2, st);

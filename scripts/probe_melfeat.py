@@ -5,7 +5,7 @@ import torch
 from mst_amd.mixing_utils import MelFeatPlan
 from mst_amd.synth import synth_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 72
-T = 441000
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 441000
 x = synth_batch(B, T, device="cuda")
 plan = MelFeatPlan(44100, 1024, 256, 128)
 for want_lm in (True, False):
@@ -19,6 +19,6 @@ for want_lm in (True, False):
         plan.forward(x, want_lm, True)
     ev1.record(); torch.cuda.synchronize()
     ms = ev0.elapsed_time(ev1) / n
-    by = B * (8 * T * 4 + (8 * 128 * 1723 * 4 if want_lm else 0) + 256)
-    print(f"B={B} logmel={want_lm}: {ms:.3f} ms/step  {B/ms*1e3:.0f} clips/s  {by/ms/1e6:.1f} GB/s algorithmic "
+    by = B * (8 * T * 4 + (8 * 128 * (1 + T // 256) * 4 if want_lm else 0) + 256)
+    print(f"B={B} T={T} logmel={want_lm}: {ms:.3f} ms/step  {B/ms*1e3:.0f} clips/s  {by/ms/1e6:.1f} GB/s algorithmic "
           f"({by/ms/1e6/8000*100:.1f}% of 8 TB/s)")
