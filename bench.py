@@ -227,9 +227,6 @@ def main():
         return e
 
     marks, pending = [], []
-    # log-mel between stage A and the HIP encoder in the pipeline-internal frame-quad layout (whole-line stores, see
-    # include/mst.h MST_LOGMEL_FQ4); the PyTorch-ROCm encoder (configs[1]) takes the reference layout
-    quads = backend == "hip" and fe.plan().supports_quads() and split // 10 == 2
     pool = [[ev() for _ in range(9)] for _ in range(a.steps)]   # events are created outside the timed region
 
     def step(timed):
@@ -242,16 +239,16 @@ def main():
                 neg = augm.augment_stems({k: v[2::3] for k, v in stems.items()}, decisions=pending.pop() if pending else None)
                 for k in stems:
                     xa[:, 2 * ("vocals", "bass", "drums", "other").index(k):][2::3, :2] = neg[k]
-                feats, logmel = fe.features_and_logmel(stems_aug, quads=quads)
+                feats, logmel = fe.features_and_logmel(stems_aug)
             elif stager is not None:
                 fut = state["fut"]
                 xin = fut.get()
                 state["k"] += 1
                 state["fut"] = stager.submit(host_batches[state["k"] % 2])   # next batch's H2D overlaps this step
-                feats, logmel = fe.features_and_logmel(ingest.stems_views(xin), quads=quads)
+                feats, logmel = fe.features_and_logmel(ingest.stems_views(xin))
                 stager.release(fut)
             else:
-                feats, logmel = fe.features_and_logmel(stems, quads=quads)
+                feats, logmel = fe.features_and_logmel(stems)
             if timed:
                 e1.record()
             if backend == "hip":

@@ -85,21 +85,6 @@ int mst_melfeat_forward_stems_pcm16(const mst_plan* plan, const int16_t* const s
                                     int B, int T, float* logmel, float* feats, void* workspace,
                                     size_t workspace_bytes, void* stream);
 
-/* Log-mel memory layouts.  REFERENCE is what torchaudio / the reference model produce and what every entry point above
- * writes.  FQ4 ("frame quads") is the layout the fused pipeline uses between stage A and the encoder: the writer emits
- * whole 128-byte lines (64 adjacent bands x 4 frames per store instruction) instead of 16-byte pieces of 64 rows that
- * lie 4*frames bytes apart, and the convolution's 8-row patch of one frame quad sits in one or two lines.
- *   REFERENCE  element (clip, ch, mel, f) at (((clip*8 + ch)*n_mels + mel)*frames + f
- *   FQ4        element (clip, ch, mel, f) at ((((clip*8 + ch)*ceil(frames/4) + f/4)*n_mels + mel)*4 + f%4 ; the pad frames
- *              of the last quad are written as 0.                                                                   */
-#define MST_LOGMEL_REFERENCE 0
-#define MST_LOGMEL_FQ4 1
-/* General entry: four stem tensors as in mst_melfeat_forward_stems, sample_type 0 = fp32 / 1 = int16 PCM, and the
- * log-mel layout.  FQ4 needs the standard configuration (n_fft 1024, hop 256, n_mels <= 128).                        */
-int mst_melfeat_forward_ex(const mst_plan* plan, const void* const stems4[4], int sample_type, long long clip_stride,
-                           int B, int T, float* logmel, int logmel_layout, float* feats, void* workspace,
-                           size_t workspace_bytes, void* stream);
-
 /* ------------------------------------------------------------------------------------------
  * Stage B: FiLM MLP + band-split Conv2D/BN/FiLM/ReLU/MaxPool x2 + attention pooling (eval).
  * Replaces: MixingFeatureEncoder.forward src/model.py:410-464, SubSpectrogramCNN.forward
@@ -159,10 +144,6 @@ size_t mst_encoder_workspace_bytes(const mst_encoder* enc, int B, int frames);
 int mst_encoder_forward(const mst_encoder* enc, const float* logmel, int frames, const float* feats,
                         int B, float* emb, const mst_encoder_taps* taps, void* workspace,
                         size_t workspace_bytes, void* stream);
-/* Same with the log-mel in the given layout (MST_LOGMEL_FQ4 needs the default 20-mel sub-bands).                */
-int mst_encoder_forward_ex(const mst_encoder* enc, const float* logmel, int logmel_layout, int frames,
-                           const float* feats, int B, float* emb, const mst_encoder_taps* taps, void* workspace,
-                           size_t workspace_bytes, void* stream);
 
 /* Training forward (first half): the same network with train-mode BatchNorm -- batch statistics over
  * (B, H, W) per (sub-band, channel), biased variance, as nn.BatchNorm2d in training mode (src/model.py:107-125 under

@@ -13,7 +13,6 @@ LIB_PATH = os.environ.get("MST_LIB", os.path.join(_HERE, "libmst.so"))  # MST_LI
 CSRC = os.path.join(_HERE, "csrc")
 
 MST_OK = 0
-LOGMEL_REFERENCE, LOGMEL_FQ4 = 0, 1   # include/mst.h: MST_LOGMEL_*
 
 
 class MstError(RuntimeError):
@@ -72,16 +71,12 @@ SYMBOLS = {
                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_melfeat_forward_stems_pcm16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_longlong, C.c_int, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
-    "mst_melfeat_forward_ex": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_longlong, C.c_int, C.c_int,
-                                         C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EncoderConfig), C.POINTER(EncoderWeights)]),
     "mst_encoder_destroy": (None, [C.c_void_p]),
     "mst_encoder_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "mst_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.POINTER(EncoderTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
-    "mst_encoder_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                         C.POINTER(EncoderTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_encoder_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),

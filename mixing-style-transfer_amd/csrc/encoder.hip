@@ -185,10 +185,6 @@ struct ConvParams {
   // (f16_scale_kernel); conv1 stores m * s as f16 hi/lo, conv2 folds 1/s into its affine.  NULL = unscaled.
   const float* f16_scale;
   const float* f16_winv;      // [nsub][COUT] inverse of the weight fragments' per-channel pre-scale
-  // conv1 input addressing (conv1_resident_kernel, conv1_f16x3_kernel): floats between rows of a channel plane, and --
-  // for the frame-quad log-mel layout (MST_LOGMEL_FQ4) -- floats between consecutive frame quads (0 = reference layout:
-  // element (row, col) at row * in_rstride + col; quads: row * 4 + (col >> 2) * in_quad + (col & 3))
-  int in_rstride, in_quad;
 };
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
@@ -577,7 +573,6 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
     nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
     col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
     coff = min(max(cin, 0), p.in_cols - 1);
-    if (p.in_quad) coff = (coff >> 2) * p.in_quad + (coff & 3);   // frame-quad layout
     rowmask = 0;
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
@@ -586,7 +581,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
       const int rin = nrow0 + r;
       const int rc = min(max(rin, 0), p.in_rows - 1);
       if (nvalid && rin == rc) rowmask |= 1ull << i;
-      const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_rstride;
+      const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols;
       pf[i] = rowp[coff];
     }
   };
@@ -838,7 +833,6 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
     nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
     col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
     coff = min(max(cin, 0), p.in_cols - 1);
-    if (p.in_quad) coff = (coff >> 2) * p.in_quad + (coff & 3);   // frame-quad layout
     rowmask = 0;
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
@@ -847,7 +841,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
       const int rin = nrow0 + r;
       const int rc = min(max(rin, 0), p.in_rows - 1);
       if (nvalid && rin == rc) rowmask |= 1ull << i;
-      pf[i] = (nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_rstride)[coff];
+      pf[i] = (nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[coff];
     }
   };
 
@@ -2355,14 +2349,7 @@ size_t mst_encoder_workspace_bytes(const mst_encoder* e, int B, int frames) {
 
 int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
                         const mst_encoder_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
-  return mst_encoder_forward_ex(e, logmel, MST_LOGMEL_REFERENCE, frames, feats, B, emb, taps, workspace, workspace_bytes, stream);
-}
-
-int mst_encoder_forward_ex(const mst_encoder* e, const float* logmel, int logmel_layout, int frames, const float* feats, int B,
-                           float* emb, const mst_encoder_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && logmel && feats && emb, "mst_encoder_forward: NULL argument");
-  MST_REQUIRE(logmel_layout == MST_LOGMEL_REFERENCE || (logmel_layout == MST_LOGMEL_FQ4 && e->sub == 2),
-              "mst_encoder_forward_ex: log-mel layout %d (the frame-quad layout needs the 20-mel sub-bands)", logmel_layout);
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
   const WsLayout L = ws_layout(e, B, frames);
   MST_REQUIRE(L.W2 >= 1, "mst_encoder_forward: clip too short for two pooling stages (frames=%d)", frames);
@@ -2396,17 +2383,9 @@ int mst_encoder_forward_ex(const mst_encoder* e, const float* logmel, int logmel
     ConvParams cp{};
     cp.in = logmel, cp.wfrag = e->w1frag, cp.aff = aff1, cp.out = pool1, cp.B = B, cp.nsub = ns;
     cp.in_rows = e->cfg.split_size, cp.in_cols = frames;
-    if (logmel_layout == MST_LOGMEL_FQ4) {   // [clip][ch][frame quad][mel][4]
-      const int fq = (frames + 3) / 4;
-      cp.in_rstride = 4, cp.in_quad = e->cfg.n_mels * 4;
-      cp.in_cstride = fq * e->cfg.n_mels * 4;
-      cp.in_bandoff = e->cfg.overlap * 4;
-    } else {
-      cp.in_rstride = frames, cp.in_quad = 0;
-      cp.in_cstride = e->cfg.n_mels * frames;
-      cp.in_bandoff = e->cfg.overlap * frames;
-    }
-    cp.in_clipstride = (long long)8 * cp.in_cstride;
+    cp.in_cstride = e->cfg.n_mels * frames;
+    cp.in_bandoff = e->cfg.overlap * frames;
+    cp.in_clipstride = (long long)8 * e->cfg.n_mels * frames;
     cp.out_rows = e->H1, cp.out_cols = L.W1;
     cp.tiles_r = e->H1;
     cp.tiles_c = e->sub == 2 ? (L.W1 + 7) / 8 : (L.W1 + 15) / 16;
@@ -2432,7 +2411,7 @@ int mst_encoder_forward_ex(const mst_encoder* e, const float* logmel, int logmel
         unsigned* xmax = reinterpret_cast<unsigned*>(ws + L.xmax);
         float* fsc = reinterpret_cast<float*>(ws + L.f16scale);
         MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
-        const long long npc = cp.in_clipstride;   // either layout: everything between two clips (pad frames are zeros)
+        const long long npc = (long long)8 * e->cfg.n_mels * frames;
         hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, npc, xmax);
         hipLaunchKernelGGL(f16_scale_kernel, dim3(B * ns), dim3(64), 0, st, aff1, e->w1norm, xmax, fsc, ns);
         cp.f16_scale = fsc;
@@ -2605,7 +2584,6 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.in_rows = e->cfg.split_size, cp.in_cols = frames;
     cp.in_cstride = e->cfg.n_mels * frames;
     cp.in_bandoff = e->cfg.overlap * frames;
-    cp.in_rstride = frames, cp.in_quad = 0;
     cp.in_clipstride = (long long)8 * e->cfg.n_mels * frames;
     cp.out_rows = e->H1, cp.out_cols = L.W1;
     cp.tiles_r = T.tr1, cp.tiles_c = T.tc1;

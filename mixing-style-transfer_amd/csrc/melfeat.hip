@@ -1119,24 +1119,9 @@ int pstride_of(const mst_plan* p) { return 4 * p->n_mels + kNumScalars; }
 
 // sliding-window kernel: frames per wave and runs per clip (a run is WPS * fpw frames; like frames_per_run_of, a
 // function of the clip length only, never of the batch size)
-int v2_fpw(const mst_plan* p, int F, int layout = MST_LOGMEL_REFERENCE) {
-  const int fpw = std::max(1, ((F + 31) / 32 + p->v2_wps - 1) / p->v2_wps);
-  if (layout != MST_LOGMEL_FQ4) return fpw;
-  // frame quads must not straddle waves: fpw is a multiple of 4.  Among those, take the one that needs the fewest
-  // frame-times per CU for the BASELINE batch (24 triplets = 72 clips on 256 CUs, one workgroup per CU at a time):
-  // rounds(fpw) * fpw with rounds = ceil(runs * 72 / 256) -- 24 at 1723 frames (7 rounds of 24 = 168 frame-times; the
-  // reference layout's 18 gives 9 x 18 = 162).  A function of the clip length only, like everything else here.
-  int best = 4;
-  long long best_cost = -1;
-  for (int w = 4; w <= 48; w += 4) {
-    const int fpr = p->v2_wps * w, runs = (F + fpr - 1) / fpr;
-    const long long cost = (long long)((runs * 72 + 255) / 256) * w;
-    if (best_cost < 0 || cost < best_cost || (cost == best_cost && abs(w - fpw) <= abs(best - fpw))) best = w, best_cost = cost;
-  }
-  return best;
-}
-int v2_runs(const mst_plan* p, int F, int layout = MST_LOGMEL_REFERENCE) {
-  const int fpr = p->v2_wps * v2_fpw(p, F, layout);
+int v2_fpw(const mst_plan* p, int F) { return std::max(1, ((F + 31) / 32 + p->v2_wps - 1) / p->v2_wps); }
+int v2_runs(const mst_plan* p, int F) {
+  const int fpr = p->v2_wps * v2_fpw(p, F);
   return (F + fpr - 1) / fpr;
 }
 
@@ -1325,7 +1310,7 @@ int mst_plan_feature_dim(const mst_plan* p) { return p ? p->feat_dim : MST_EINVA
 size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
   if (!p || B <= 0 || T <= 0) return 0;
   const int F = 1 + T / p->hop;
-  const int runs = std::max(runs_per_clip(p, B, F), p->v2_ok ? std::max(v2_runs(p, F), v2_runs(p, F, MST_LOGMEL_FQ4)) : 0);
+  const int runs = std::max(runs_per_clip(p, B, F), p->v2_ok ? v2_runs(p, F) : 0);
   return mst::align_up((size_t)B * runs * pstride_of(p) * sizeof(float), 256);
 }
 
@@ -1333,8 +1318,7 @@ size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
 
 namespace {
 int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pcm16, long long clip_stride, int B, int T,
-                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream,
-                         int layout = MST_LOGMEL_REFERENCE);
+                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream);
 }
 
 extern "C" {
@@ -1368,24 +1352,13 @@ int mst_melfeat_forward_stems_pcm16(const mst_plan* p, const int16_t* const stem
   return melfeat_forward_impl(p, four, true, clip_stride, B, T, logmel, feats, workspace, workspace_bytes, stream);
 }
 
-int mst_melfeat_forward_ex(const mst_plan* p, const void* const stems4[4], int sample_type, long long clip_stride, int B,
-                           int T, float* logmel, int logmel_layout, float* feats, void* workspace, size_t workspace_bytes,
-                           void* stream) {
-  MST_REQUIRE(p && stems4, "mst_melfeat_forward_ex: NULL plan/stems");
-  MST_REQUIRE(sample_type == 0 || sample_type == 1, "mst_melfeat_forward_ex: sample_type %d (0 fp32, 1 int16 PCM)", sample_type);
-  const void* four[4] = {stems4[0], stems4[1], stems4[2], stems4[3]};
-  return melfeat_forward_impl(p, four, sample_type == 1, clip_stride, B, T, logmel, feats, workspace, workspace_bytes, stream,
-                              logmel_layout);
-}
-
 }  // extern "C"
 
 namespace {
 
 int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pcm16, long long clip_stride, int B, int T,
-                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream, int layout) {
+                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(p && stems4[0] && stems4[1] && stems4[2] && stems4[3], "mst_melfeat_forward: NULL plan/stems");
-  MST_REQUIRE(layout == MST_LOGMEL_REFERENCE || layout == MST_LOGMEL_FQ4, "mst_melfeat_forward: unknown log-mel layout %d", layout);
   MST_REQUIRE(clip_stride >= 2LL * T, "mst_melfeat_forward_stems: clip_stride %lld < 2*T", clip_stride);
   MST_REQUIRE(B > 0 && T > p->n_fft / 2, "mst_melfeat_forward: need B>0 and T > n_fft/2 (reflect pad); B=%d T=%d", B, T);
   MST_REQUIRE((long long)B * 8 * T < (1LL << 40), "mst_melfeat_forward: input too large");
@@ -1427,8 +1400,6 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
   // sliding-window kernel for the standard configuration (MST_STAGE_A=spw | generic selects the older kernels)
   const char* which = getenv("MST_STAGE_A");
   const bool use_v2 = p->v2_ok && !(which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) && !getenv("MST_MELFEAT_GENERIC");
-  MST_REQUIRE(layout == MST_LOGMEL_REFERENCE || use_v2,
-              "mst_melfeat_forward_ex: the frame-quad log-mel layout needs the standard configuration (n_fft 1024, hop 256, <= 128 mels)");
   if (use_v2) {
     K2Params k2{};
     for (int i = 0; i < 4; ++i) k2.stem[i] = stems4[i];
@@ -1438,8 +1409,7 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     k2.B = B, k2.T = T, k2.F = F, k2.M = p->n_mels;
     k2.nslot = p->v2_nslot, k2.segw_count = p->v2_segw_count;
     for (int r = 0; r < 3; ++r) k2.glen[r] = p->v2_glen[r], k2.goff[r] = p->v2_goff[r];
-    k2.layout = layout;
-    k2.fpw = v2_fpw(p, F, layout), k2.runs_per_clip = v2_runs(p, F, layout), k2.pstride = pstride_of(p);
+    k2.fpw = v2_fpw(p, F), k2.runs_per_clip = v2_runs(p, F), k2.pstride = pstride_of(p);
     kp.runs_per_clip = k2.runs_per_clip;   // the finalise kernel walks the same records
     const int wps = p->v2_wps;
     const size_t lds2 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows) * 64 + p->v2_segw_count + 4 * wps * mstpk::kScr) * sizeof(float2) +

@@ -63,29 +63,6 @@ def melscale_fbanks_htk(n_freqs: int, n_mels: int, sample_rate: int) -> torch.Te
     return torch.max(torch.zeros(1), torch.min(lower, upper))
 
 
-class QuadLogMel:
-    """Log-mel in the frame-quad layout of the fused pipeline (include/mst.h MST_LOGMEL_FQ4): `data` is
-    (B, 8, ceil(F/4), n_mels, 4) -- stage A writes whole 128-byte lines and the convolution's patch of a frame quad sits
-    in one or two lines -- with the pad frames of the last quad zero.  `.reference()` gives the (B, 8, n_mels, F) tensor of
-    the reference API (a copy)."""
-
-    def __init__(self, data: torch.Tensor, frames: int):
-        self.data, self.frames = data, frames
-
-    @property
-    def shape(self):
-        B, ch, fq, M, _ = self.data.shape
-        return torch.Size((B, ch, M, self.frames))
-
-    @property
-    def device(self):
-        return self.data.device
-
-    def reference(self) -> torch.Tensor:
-        B, ch, fq, M, _ = self.data.shape
-        return self.data.permute(0, 1, 3, 2, 4).reshape(B, ch, M, fq * 4)[..., :self.frames].contiguous()
-
-
 class MelFeatPlan:
     """Owns an `mst_plan` (device tables for one STFT/mel configuration) and a cached workspace."""
 
@@ -120,14 +97,9 @@ class MelFeatPlan:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws, need
 
-    def supports_quads(self):
-        """The frame-quad log-mel layout exists for the sliding-window kernel: n_fft 1024, hop 256, <= 128 mels."""
-        return self.n_fft == 1024 and self.hop_length == 256 and self.n_mels <= 128
-
-    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True, quads=False):
+    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True):
         """{stem: (B,2,T) | (2,T)} fp32 CUDA -> (logmel, feats) without concatenating the stems: the kernel reads the
-        four tensors in place (views of one packed (B,8,T) tensor work too, any common clip stride).
-        quads=True: the log-mel comes back as a QuadLogMel (the pipeline-internal layout) instead of (B,8,M,F)."""
+        four tensors in place (views of one packed (B,8,T) tensor work too, any common clip stride)."""
         parts = [stems_dict[s] for s in STEMS]
         if parts[0].dim() == 2:
             parts = [q.unsqueeze(0) for q in parts]
@@ -139,30 +111,22 @@ class MelFeatPlan:
                  and q.stride(0) == parts[0].stride(0) for q in parts) and (B == 1 or parts[0].stride(0) >= 2 * T) \
             and dt in (torch.float32, torch.int16)
         if not ok:
-            if not all(q.dtype == torch.int16 for q in parts):
-                parts = [q.float() for q in parts]
-            x8 = torch.cat(parts, dim=1)
-            return self.forward_stems({s: x8[:, 2 * i:2 * i + 2] for i, s in enumerate(STEMS)}, want_logmel, want_feats,
-                                      quads)
+            if all(q.dtype == torch.int16 for q in parts):
+                return self.forward(torch.cat(parts, dim=1), want_logmel, want_feats)
+            return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats)
         dev = parts[0].device
         F = self.frames(T)
-        quads = bool(quads and want_logmel)
-        if quads and not self.supports_quads():
-            raise _lib.MstError("the frame-quad log-mel layout needs n_fft 1024, hop 256, n_mels <= 128")
-        if quads:
-            logmel = torch.empty(B, 8, (F + 3) // 4, self.n_mels, 4, dtype=torch.float32, device=dev)
-        else:
-            logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=dev) if want_logmel else None
+        logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=dev) if want_logmel else None
         feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=dev) if want_feats else None
         ws, need = self._workspace(B, T, dev)
         ptrs = (C.c_void_p * 4)(*[q.data_ptr() for q in parts])
         stride = parts[0].stride(0) if B > 1 else 2 * T
         L = _lib.lib()
+        fn = L.mst_melfeat_forward_stems_pcm16 if dt == torch.int16 else L.mst_melfeat_forward_stems
         with torch.cuda.device(dev):
-            _lib.check(L.mst_melfeat_forward_ex(self._h, ptrs, 1 if dt == torch.int16 else 0, stride, B, T, _lib.dptr(logmel),
-                                                _lib.LOGMEL_FQ4 if quads else _lib.LOGMEL_REFERENCE, _lib.dptr(feats),
-                                                _lib.dptr(ws), need, _lib.stream_ptr(dev)), "mst_melfeat_forward_ex")
-        return (QuadLogMel(logmel, F) if quads else logmel), feats
+            _lib.check(fn(self._h, ptrs, stride, B, T, _lib.dptr(logmel), _lib.dptr(feats), _lib.dptr(ws), need,
+                          _lib.stream_ptr(dev)), "mst_melfeat_forward_stems")
+        return logmel, feats
 
     def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True):
         """stems8 (B, 8, T) CUDA, fp32 or int16 PCM (value = s / 32768) -> (logmel (B,8,M,F) | None, feats (B,Fd) | None)."""
@@ -236,10 +200,9 @@ class MixingFeatureExtractor:
                                      self.n_spectral_bins if self.use_detailed_spectral else 0)
         return self._plan
 
-    def features_and_logmel(self, stems_dict, quads=False):
-        """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F)); quads=True: the log-mel as a
-        QuadLogMel (pipeline-internal layout, what `MixingStyleEncoder.forward_from_logmel` consumes fastest)."""
-        lm, f = self.plan().forward_stems(stems_dict, True, True, quads)
+    def features_and_logmel(self, stems_dict):
+        """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F))."""
+        lm, f = self.plan().forward_stems(stems_dict, True, True)
         return f, lm
 
     def resolve_features(self, stems_dict, features):

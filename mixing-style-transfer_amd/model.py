@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .mixing_utils import (STEMS, MelFeatPlan, QuadLogMel, detailed_bins_for_feature_dim, hann_window, is_deferred,
+from .mixing_utils import (STEMS, MelFeatPlan, detailed_bins_for_feature_dim, hann_window, is_deferred,
                            melscale_fbanks_htk, stems_to_tensor)
 
 
@@ -331,18 +331,9 @@ class HipEncoder:
         return dy, dbn
 
     def forward(self, logmel, feats, taps=False, events=None):
-        """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h).
-        logmel: (B, 8, n_mels, frames) tensor or a QuadLogMel (frame-quad layout, 20-mel sub-bands only)."""
+        """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
         B, _, M, Fr = logmel.shape
         L = _lib.lib()
-        layout = _lib.LOGMEL_REFERENCE
-        if isinstance(logmel, QuadLogMel):
-            if self.sub != 2:
-                logmel = logmel.reference()
-            else:
-                layout, logmel = _lib.LOGMEL_FQ4, logmel.data
-        if layout == _lib.LOGMEL_REFERENCE:
-            logmel = logmel.contiguous().float()
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
         if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=logmel.device)
@@ -361,9 +352,9 @@ class HipEncoder:
                 tp.events[i] = ev.cuda_event
             t = C.byref(tp)
         with torch.cuda.device(logmel.device):
-            _lib.check(L.mst_encoder_forward_ex(self._h, _lib.dptr(logmel), layout, Fr, _lib.dptr(feats.contiguous().float()),
-                                                B, _lib.dptr(emb), t, _lib.dptr(self._ws), need,
-                                                _lib.stream_ptr(logmel.device)), "mst_encoder_forward_ex")
+            _lib.check(L.mst_encoder_forward(self._h, _lib.dptr(logmel), Fr, _lib.dptr(feats.contiguous().float()), B,
+                                             _lib.dptr(emb), t, _lib.dptr(self._ws), need,
+                                             _lib.stream_ptr(logmel.device)), "mst_encoder_forward")
         return (emb, out) if taps else emb
 
 
@@ -537,11 +528,7 @@ class MixingStyleEncoder(nn.Module):
         return None
 
     def forward_from_logmel(self, logmel, mixing_features):
-        """logmel: (B, 8, n_mels, frames), or a QuadLogMel on the eval path (the training trunk and the PyTorch-ROCm
-        path take the reference layout: a QuadLogMel is converted)."""
         auto = self._needs_autograd(mixing_features)
-        if isinstance(logmel, QuadLogMel) and not (self.encoder_backend == "hip" and not auto and not self.training):
-            logmel = logmel.reference()
         if self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict"):
             why = self._hip_trunk_refusal(logmel)
             if why is None:
@@ -567,12 +554,9 @@ class MixingStyleEncoder(nn.Module):
         hold real values are used as given."""
         bins = detailed_bins_for_feature_dim(self.film_encoder.feature_dim)
         pre = self.audio_encoder.mel_preprocessor
-        quads = self.encoder_backend == "hip" and not self.training and not self._needs_autograd(mixing_features) and \
-            self.audio_encoder.split_size // 10 == 2
         with torch.no_grad():
             if bins is not None and (bins == 0 or bins <= self.audio_encoder.n_mels):
-                plan = pre.plan(bins)
-                logmel, feats = plan.forward_stems(stems_dict, True, True, quads and plan.supports_quads())
+                logmel, feats = pre.plan(bins).forward_stems(stems_dict, True, True)
             else:   # no feature layout of this size exists: the caller must bring real features
                 logmel, feats = pre(stems_dict), None
         mf = mixing_features.to(logmel.device)

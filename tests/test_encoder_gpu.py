@@ -576,29 +576,3 @@ def test_training_step_is_bit_deterministic():
     diff = [n for n in g0 if not torch.equal(g0[n], g1[n])]
     assert not diff, f"{len(diff)} gradient tensors differ between two identical steps, e.g. {diff[:3]}"
     assert all(torch.equal(s0[n], s1[n]) for n in s0)
-
-
-@pytest.mark.parametrize("precision", ["fp32", "f16x3-all"])
-def test_encoder_reads_the_frame_quad_layout(precision):
-    """conv1 (exact and split-precision) fed from the frame-quad log-mel equals conv1 fed from the reference layout:
-    same values, same arithmetic order -- bit for bit."""
-    g = np.load(os.path.join(G, "encoder.npz"))
-    model, sd = build_model(cases.CFG_DEFAULT)
-    model.conv1_precision = precision
-    x = torch.stack([cases.synth_clip(c, 66150 + 512) for c in (0, 1, 2)], 0)     # 261 frames: a ragged last quad
-    feats = torch.from_numpy(g["default_short.features"])[[0, 1, 0]].cuda()
-    with torch.no_grad():
-        plan = model.audio_encoder.mel_preprocessor.plan()
-        lm_ref, _ = plan.forward_stems(omel.tensor_to_stems_dict(x.cuda()), True, False)
-        lm_q, _ = plan.forward_stems(omel.tensor_to_stems_dict(x.cuda()), True, False, quads=True)
-        e_ref, t_ref = model.hip_encoder().forward(lm_ref, feats, taps=True)
-        e_q, t_q = model.hip_encoder().forward(lm_q, feats, taps=True)
-    assert torch.equal(t_q["pool1"], t_ref["pool1"]) and torch.equal(t_q["pool_in"], t_ref["pool_in"])
-    assert torch.equal(e_q, e_ref)
-    # and the contract call (which takes the quad layout by itself) against the oracle
-    from mst_amd.mixing_utils import deferred_features
-    with torch.no_grad():
-        emb = model(omel.tensor_to_stems_dict(x.cuda()), torch.stack([deferred_features(64)] * 3).cuda())
-    from oracle import features as ofeat
-    ref = oenc.encoder_forward(sd, x, ofeat.extract_all_features(x))
-    close(emb.cpu(), ref, 2e-4 if precision == "fp32" else 3e-4)

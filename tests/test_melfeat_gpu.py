@@ -278,28 +278,3 @@ def test_two_stage_a_kernels_agree_on_ragged_run_partitions(T):
     # batch independence, bit for bit, for both kernels
     f1, lm1 = run(x[1:2], ext)
     assert torch.equal(f1[0], f_spw[1]) and torch.equal(lm1[0], lm_spw[1])
-
-
-@pytest.mark.parametrize("T,B,pcm", [(441000, 2, False), (256 * 55 + 130, 3, False), (4096 + 256 * 2, 1, False), (66150, 2, True)])
-def test_frame_quad_layout_is_the_same_log_mel(T, B, pcm):
-    """The pipeline-internal log-mel layout (MST_LOGMEL_FQ4: [B][8][ceil(F/4)][M][4], whole-line stores) holds exactly the
-    values of the reference layout -- bit for bit, pad frames of the last quad zero -- and the features agree to fp32
-    partial-sum rounding (the run partition differs: frames per wave are a multiple of 4 there)."""
-    from mst_amd import ingest
-    x = torch.stack([cases.synth_clip(20 + c, T) for c in range(B)], 0)
-    xin = ingest.float_to_pcm16(x).cuda() if pcm else x.cuda()
-    d = omel.tensor_to_stems_dict(xin)
-    ext = fe()
-    f_ref, lm_ref = ext.features_and_logmel(d)
-    f_q, lm_q = ext.features_and_logmel(d, quads=True)
-    torch.cuda.synchronize()
-    F = 1 + T // 256
-    assert tuple(lm_q.data.shape) == (B, 8, (F + 3) // 4, 128, 4) and tuple(lm_q.shape) == (B, 8, 128, F)
-    assert torch.equal(lm_q.reference(), lm_ref)
-    if F % 4:
-        pad = lm_q.data[:, :, -1, :, F % 4:]
-        assert not pad.any()
-    check_feats(f_q.cpu(), f_ref.cpu().numpy(), rtol=2e-6, atol=2e-6, name="features, quad vs reference layout")
-    # batch independence in the quad layout as well
-    f1, lm1 = ext.features_and_logmel({k: v[B - 1:B] for k, v in d.items()}, quads=True)
-    assert torch.equal(f1[0], f_q[B - 1]) and torch.equal(lm1.data[0], lm_q.data[B - 1])

@@ -28,9 +28,9 @@ def _count_stage_a(monkeypatch):
     calls = []
     real = MelFeatPlan.forward_stems
 
-    def counted(self, stems_dict, want_logmel=True, want_feats=True, quads=False):
-        calls.append((want_logmel, want_feats, next(iter(stems_dict.values())).shape[0], quads))
-        return real(self, stems_dict, want_logmel, want_feats, quads)
+    def counted(self, stems_dict, want_logmel=True, want_feats=True):
+        calls.append((want_logmel, want_feats, next(iter(stems_dict.values())).shape[0]))
+        return real(self, stems_dict, want_logmel, want_feats)
     monkeypatch.setattr(MelFeatPlan, "forward_stems", counted)
     return calls
 
@@ -97,7 +97,7 @@ def test_reference_train_and_validate_loops_run_unchanged(tmp_path, monkeypatch)
             losses.append(loss.detach().item())
             batches += 1
     assert batches == 2 and all(np.isfinite(losses)) and embeddings.shape == (10, 768)
-    assert [c[:3] for c in calls] == [(True, True, 10)] * 2, calls            # stage A ran ONCE per batch, features + log-mel together
+    assert calls == [(True, True, 10)] * 2, calls            # stage A ran ONCE per batch, features + log-mel together
     moved = [k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])]
     assert len(moved) > 0.9 * len(before), f"only {len(moved)} of {len(before)} parameters changed"
     assert len(model._warned) == 0, model._warned                  # the hand-written trunk took the training calls
@@ -122,7 +122,7 @@ def test_reference_train_and_validate_loops_run_unchanged(tmp_path, monkeypatch)
             loss = criterion(embeddings, song_labels)
             assert np.isfinite(loss.item())
             # bit for bit what the explicit two-call form gives (same kernels, same launch shapes)
-            feats, logmel = ext.features_and_logmel(stems_dict, quads=True)   # the pipeline-internal log-mel layout
+            feats, logmel = ext.features_and_logmel(stems_dict)
             assert torch.equal(embeddings, model.forward_from_logmel(logmel, feats))
             # real features passed in are used as given: rows 0..4 real (perturbed), rows 5..9 deferred
             mixed = mixing_features.clone()
@@ -156,6 +156,6 @@ def test_deferred_rows_need_a_feature_layout():
     m = MixingStyleEncoder(feature_dim=180).cuda().eval()
     ext = MixingFeatureExtractor(use_detailed_spectral=True, n_spectral_bins=32)
     with torch.no_grad():
-        feats, logmel = ext.features_and_logmel(stems, quads=True)
+        feats, logmel = ext.features_and_logmel(stems)
         assert feats.shape == (1, 180)
         assert torch.equal(m(stems, deferred_features(180)[None].cuda()), m.forward_from_logmel(logmel, feats))
