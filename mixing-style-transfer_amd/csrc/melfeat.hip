@@ -1048,6 +1048,7 @@ template <int NFFT>
 constexpr int tw_count_of() { return FftPlan<NFFT / 2>::TW; }
 
 #include "melfeat_v2.inc"
+#include "melfeat_v2_2048.inc"
 
 }  // namespace
 
@@ -1069,6 +1070,14 @@ struct mst_plan {
   // sliding-window kernel (melfeat_v2.inc): packed-FFT twiddles and the segment form of the sparse mel table
   bool v2_ok = false;
   int v2_nslot = 0, v2_glen[3] = {0, 0, 0}, v2_goff[3] = {0, 0, 0}, v2_segw_count = 0, v2_wps = 3;
+  // n_fft 2048 / hop 512 variant (melfeat_v2_2048.inc): W_2048 combine twiddles and the piece form of the mel table
+  bool v4_ok = false;
+  int v4_nslot = 0, v4_glen[4] = {0, 0, 0, 0}, v4_goff[4] = {0, 0, 0, 0}, v4_segw_count = 0, v4_maxcnt = 0;
+  float2* d_v4_tw4 = nullptr;
+  float2* d_v4_segw = nullptr;
+  int* d_v4_pstart = nullptr;
+  int* d_v4_pid = nullptr;
+  int* d_v4_bandtab = nullptr;
   float2* d_v2_tw2 = nullptr;
   float2* d_v2_tw3 = nullptr;
   float2* d_v2_segw = nullptr;
@@ -1122,6 +1131,99 @@ int pstride_of(const mst_plan* p) { return 4 * p->n_mels + kNumScalars; }
 int v2_fpw(const mst_plan* p, int F) { return std::max(1, ((F + 31) / 32 + p->v2_wps - 1) / p->v2_wps); }
 int v2_runs(const mst_plan* p, int F) {
   const int fpr = p->v2_wps * v2_fpw(p, F);
+  return (F + fpr - 1) / fpr;
+}
+
+// seg(k), falling weight wl(k) (band seg - 1) and rising weight wh(k) (band seg) of every bin; false unless every bin feeds
+// at most two ADJACENT bands and the segments are contiguous bin ranges.
+bool segment_bins(const float* fb, int n_bins, int M, std::vector<int>& seg, std::vector<float>& wl, std::vector<float>& wh) {
+  std::vector<int> peak(M, -1);
+  for (int m = 0; m < M; ++m) {
+    float best = 0.f;
+    for (int k = 0; k < n_bins; ++k)
+      if (fb[(size_t)k * M + m] > best) best = fb[(size_t)k * M + m], peak[m] = k;
+  }
+  seg.assign(n_bins, 0), wl.assign(n_bins, 0.f), wh.assign(n_bins, 0.f);
+  int prev = 0;
+  for (int k = 0; k < n_bins; ++k) {
+    int b0 = -1, b1 = -1, cnt = 0;
+    for (int m = 0; m < M; ++m)
+      if (fb[(size_t)k * M + m] != 0.0f) {
+        if (cnt == 0) b0 = m;
+        b1 = m;
+        ++cnt;
+      }
+    if (cnt > 2 || (cnt == 2 && b1 != b0 + 1)) return false;
+    int s = prev;
+    if (cnt == 2) {
+      s = b1, wl[k] = fb[(size_t)k * M + b0], wh[k] = fb[(size_t)k * M + b1];
+    } else if (cnt == 1) {
+      if (k <= peak[b0]) s = b0, wh[k] = fb[(size_t)k * M + b0];
+      else s = b0 + 1, wl[k] = fb[(size_t)k * M + b0];
+    }
+    if (s < prev) return false;
+    seg[k] = prev = s;
+  }
+  return true;
+}
+
+// Piece form for melfeat_v2_2048_kernel: segments cut into pieces of at most 16 bins (numbered in segment order, so the
+// pieces of a segment are consecutive), pieces dealt to (slot, lane) by length, and per band the piece ranges of its
+// rising segment (b) and of its falling segment (b + 1).
+bool v4_build_pieces(mst_plan* p, const float* fb, std::vector<float2>& segw, std::vector<int>& pstart, std::vector<int>& pid,
+                     std::vector<int>& bandtab) {
+  const int M = p->n_mels, n_bins = p->n_fft / 2 + 1;
+  if (p->n_fft != 2048 || M > 128) return false;
+  std::vector<int> seg;
+  std::vector<float> wl, wh;
+  if (!segment_bins(fb, n_bins, M, seg, wl, wh)) return false;
+  const int nseg = M + 1;
+  std::vector<int> start(nseg, 0), len(nseg, 0);
+  for (int k = n_bins - 1; k >= 0; --k) start[seg[k]] = k, ++len[seg[k]];
+  struct Piece { int start, len; };
+  std::vector<Piece> pieces;
+  std::vector<int> first(nseg, 0), cnt(nseg, 0);
+  for (int sg = 0; sg < nseg; ++sg) {
+    first[sg] = (int)pieces.size();
+    for (int o = 0; o < len[sg]; o += 16) pieces.push_back({start[sg] + o, std::min(16, len[sg] - o)}), ++cnt[sg];
+  }
+  const int np = (int)pieces.size();
+  if (np > 135) return false;   // exchange arrays hold 136 entries, the last one is the dump slot
+  std::vector<int> order(np);
+  for (int i = 0; i < np; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pieces[a].len > pieces[b].len; });
+  p->v4_nslot = (np + 63) / 64;
+  if (p->v4_nslot > 4) return false;
+  pstart.assign((size_t)p->v4_nslot * 64, 0);
+  pid.assign((size_t)p->v4_nslot * 64, 135);
+  int off = 0;
+  for (int r = 0; r < p->v4_nslot; ++r) {
+    int gl = 0;
+    for (int lane = 0; lane < 64 && r * 64 + lane < np; ++lane) gl = std::max(gl, pieces[order[r * 64 + lane]].len);
+    p->v4_glen[r] = gl, p->v4_goff[r] = off;
+    segw.resize((size_t)(off + gl) * 64, make_float2(0.f, 0.f));
+    for (int lane = 0; lane < 64 && r * 64 + lane < np; ++lane) {
+      const int pc = order[r * 64 + lane];
+      pstart[(size_t)r * 64 + lane] = pieces[pc].start, pid[(size_t)r * 64 + lane] = pc;
+      for (int i = 0; i < pieces[pc].len; ++i)
+        segw[(size_t)(off + i) * 64 + lane] = make_float2(wl[pieces[pc].start + i], wh[pieces[pc].start + i]);
+    }
+    off += gl;
+  }
+  if (segw.size() & 1) segw.push_back(make_float2(0.f, 0.f));
+  if (segw.empty()) segw.resize(2, make_float2(0.f, 0.f));
+  p->v4_segw_count = (int)segw.size();
+  bandtab.assign(128, 0);
+  p->v4_maxcnt = 0;
+  for (int b = 0; b < M; ++b) {
+    bandtab[(b >> 6) * 64 + (b & 63)] = first[b] | (cnt[b] << 8) | (first[b + 1] << 16) | (cnt[b + 1] << 24);
+    p->v4_maxcnt = std::max(p->v4_maxcnt, std::max(cnt[b], cnt[b + 1]));
+  }
+  return true;
+}
+int v4_fpw(int F) { return std::max(1, ((F + 31) / 32 + 1) / 2); }
+int v4_runs(int F) {
+  const int fpr = 2 * v4_fpw(F);
   return (F + fpr - 1) / fpr;
 }
 
@@ -1282,6 +1384,30 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
       }
     }
   }
+  {   // n_fft 2048 / hop 512 variant
+    std::vector<float2> segw, t2(mstpk::kTw2Rows * 64), t3(mstpk::kTw3Rows * 64), t4(16 * 64);
+    std::vector<int> pstart, pid, bandtab;
+    p->v4_ok = n_fft == 2048 && hop == 512 && v4_build_pieces(p, fb, segw, pstart, pid, bandtab);
+    if (p->v4_ok) {
+      mstpk::fill_twiddles_host(t2.data(), t3.data());
+      for (int t = 0; t < 8; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int u = 0; u < 2; ++u) {
+            const int k = (u ? (lane ? 128 - lane : 64) : lane) + 128 * t;
+            const double a = -2.0 * M_PI * (double)k / 2048.0;
+            t4[(size_t)(8 * u + t) * 64 + lane] = make_float2((float)cos(a), (float)sin(a));
+          }
+      int rc2;
+      if ((rc2 = mst::upload(&p->d_v2_tw2, t2.data(), t2.size())) || (rc2 = mst::upload(&p->d_v2_tw3, t3.data(), t3.size())) ||
+          (rc2 = mst::upload(&p->d_v4_tw4, t4.data(), t4.size())) || (rc2 = mst::upload(&p->d_v4_segw, segw.data(), segw.size())) ||
+          (rc2 = mst::upload(&p->d_v4_pstart, pstart.data(), pstart.size())) ||
+          (rc2 = mst::upload(&p->d_v4_pid, pid.data(), pid.size())) ||
+          (rc2 = mst::upload(&p->d_v4_bandtab, bandtab.data(), bandtab.size()))) {
+        mst_plan_destroy(p);
+        return rc2;
+      }
+    }
+  }
   int rc;
   if ((rc = mst::upload(&p->d_window, window, (size_t)n_fft)) || (rc = mst::upload(&p->d_tw, tw.data(), tw.size())) ||
       (rc = mst::upload(&p->d_tw2, tw2.data(), tw2.size())) ||
@@ -1301,6 +1427,8 @@ void mst_plan_destroy(mst_plan* p) {
       (void)hipFree(p->d_lanebands);
   (void)hipFree(p->d_v2_tw2), (void)hipFree(p->d_v2_tw3), (void)hipFree(p->d_v2_segw), (void)hipFree(p->d_v2_segstart),
       (void)hipFree(p->d_v2_segid);
+  (void)hipFree(p->d_v4_tw4), (void)hipFree(p->d_v4_segw), (void)hipFree(p->d_v4_pstart), (void)hipFree(p->d_v4_pid),
+      (void)hipFree(p->d_v4_bandtab);
   delete p;
 }
 
@@ -1310,7 +1438,7 @@ int mst_plan_feature_dim(const mst_plan* p) { return p ? p->feat_dim : MST_EINVA
 size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
   if (!p || B <= 0 || T <= 0) return 0;
   const int F = 1 + T / p->hop;
-  const int runs = std::max(runs_per_clip(p, B, F), p->v2_ok ? v2_runs(p, F) : 0);
+  const int runs = std::max(runs_per_clip(p, B, F), p->v2_ok ? v2_runs(p, F) : (p->v4_ok ? v4_runs(F) : 0));
   return mst::align_up((size_t)B * runs * pstride_of(p) * sizeof(float), 256);
 }
 
@@ -1400,7 +1528,24 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
   // sliding-window kernel for the standard configuration (MST_STAGE_A=spw | generic selects the older kernels)
   const char* which = getenv("MST_STAGE_A");
   const bool use_v2 = p->v2_ok && !(which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) && !getenv("MST_MELFEAT_GENERIC");
-  if (use_v2) {
+  const bool use_v4 = p->v4_ok && !(which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) && !getenv("MST_MELFEAT_GENERIC");
+  if (use_v4) {
+    K4Params k4{};
+    for (int i = 0; i < 4; ++i) k4.stem[i] = stems4[i];
+    k4.clip_stride = clip_stride, k4.logmel = logmel, k4.partials = reinterpret_cast<float*>(workspace);
+    k4.window = p->d_window, k4.tw2 = p->d_v2_tw2, k4.tw3 = p->d_v2_tw3, k4.tw4 = p->d_v4_tw4, k4.segw = p->d_v4_segw;
+    k4.pstart = p->d_v4_pstart, k4.pid = p->d_v4_pid, k4.bandtab = p->d_v4_bandtab;
+    k4.B = B, k4.T = T, k4.F = F, k4.M = p->n_mels;
+    k4.nslot = p->v4_nslot, k4.segw_count = p->v4_segw_count, k4.maxcnt = p->v4_maxcnt;
+    for (int r = 0; r < 4; ++r) k4.glen[r] = p->v4_glen[r], k4.goff[r] = p->v4_goff[r];
+    k4.fpw = v4_fpw(F), k4.runs_per_clip = v4_runs(F), k4.pstride = pstride_of(p);
+    kp.runs_per_clip = k4.runs_per_clip;
+    const size_t lds4 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows + 16) * 64 + p->v4_segw_count + 1024 + 8 * v4::kScr4) * sizeof(float2) +
+                        (size_t)v4::kWPS * v4::kBLK * 4 * 128 * sizeof(float);
+    MST_REQUIRE(lds4 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds4);
+    const int grid4 = B * k4.runs_per_clip;
+    e = pcm16 ? launch_melfeat_v2_2048<short>(k4, grid4, lds4, st) : launch_melfeat_v2_2048<float>(k4, grid4, lds4, st);
+  } else if (use_v2) {
     K2Params k2{};
     for (int i = 0; i < 4; ++i) k2.stem[i] = stems4[i];
     k2.clip_stride = clip_stride, k2.logmel = logmel, k2.partials = reinterpret_cast<float*>(workspace);

@@ -278,3 +278,26 @@ def test_two_stage_a_kernels_agree_on_ragged_run_partitions(T):
     # batch independence, bit for bit, for both kernels
     f1, lm1 = run(x[1:2], ext)
     assert torch.equal(f1[0], f_spw[1]) and torch.equal(lm1[0], lm_spw[1])
+
+
+def test_real_music_log_mel_at_n_fft_2048_matches_pocketfft_noise():
+    """The reference's working launcher configuration (scripts/train_baseline.sh: 2048 / 512 / 80 mels) on real music
+    (the two 10 s crops of assets/song_A.wav).  Round 1's even/odd-packed real FFT carried 3-10x pocketfft's rounding noise
+    in the top octave of low-passed stems; the 2048-point sliding-window kernel (two 1024-point FFTs + one DIT step on the
+    L + i s R packing) has to meet the same measured-noise criterion as the 1024-point kernel, and the features 1e-4."""
+    x = cases.song_a_clips()
+    ext = fe(n_fft=2048, hop_length=512, n_mels=80)
+    f, lm = run(x, ext)
+    assert tuple(lm.shape) == (2, 8, 80, 1 + 441000 // 512)
+    rf, rmel = ofeat.extract_all_features(x, 44100, 2048, 512, 80, return_mel=True)
+    check_logmel(lm, torch.log(rmel + 1e-10), x=x, cfg=(44100, 2048, 512, 80))
+    check_feats(f, rf)
+    # batch independence and the generic kernel as a second opinion on bookkeeping (ragged run partition at 862 frames)
+    f1, lm1 = run(x[1:2], ext)
+    assert torch.equal(f1[0], f[1]) and torch.equal(lm1[0], lm[1])
+    os.environ["MST_MELFEAT_GENERIC"] = "1"
+    try:
+        fg, lmg = run(x, ext)
+    finally:
+        os.environ.pop("MST_MELFEAT_GENERIC", None)
+    check_feats(f, fg.numpy())
