@@ -185,6 +185,9 @@ struct ConvParams {
   // (f16_scale_kernel); conv1 stores m * s as f16 hi/lo, conv2 folds 1/s into its affine.  NULL = unscaled.
   const float* f16_scale;
   const float* f16_winv;      // [nsub][COUT] inverse of the weight fragments' per-channel pre-scale
+  // conv1_resident_kernel<2> only: 1 = MaxPool2d((1, 5)) on its 2 x 40 tiles (16-mel sub-bands: split // 10 == 1) -- the
+  // lane's 10 accumulator positions are two 1 x 5 windows, one per tile row, instead of one 2 x 5 window; 0 / 2 = (2, 5)
+  int pool_h;
 };
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
@@ -683,14 +686,28 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         const float2 ac = aff[ch];
 #pragma unroll
         for (int wv = 0; wv < C::WPG; ++wv) {
-          float m = 0.f;
-#pragma unroll
-          for (int pos = 0; pos < C::WIN; ++pos) {
-            const int e = wv * C::WIN + pos;
-            m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
-          }
           const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
-          if (pc < p.out_cols) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
+          if (SUB == 2 && p.pool_h == 1) {   // two 1 x 5 windows: positions 0..4 are tile row 0, 5..9 tile row 1
+#pragma unroll
+            for (int hr = 0; hr < 2; ++hr) {
+              float m = 0.f;
+#pragma unroll
+              for (int pos = 0; pos < 5; ++pos) {
+                const int e = wv * C::WIN + 5 * hr + pos;
+                m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
+              }
+              if (pc < p.out_cols && 2 * cur.tr + hr < p.out_rows)
+                orow[(size_t)ch * p.out_rows * p.out_cols + (size_t)(cur.tr + hr) * p.out_cols + pc] = m;   // orow is at row tr: + tr + hr
+            }
+          } else {
+            float m = 0.f;
+#pragma unroll
+            for (int pos = 0; pos < C::WIN; ++pos) {
+              const int e = wv * C::WIN + pos;
+              m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
+            }
+            if (pc < p.out_cols) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
+          }
         }
       }
     }
@@ -2422,8 +2439,16 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
       if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       err = hipGetLastError();
-    } else if (e->sub == 2 && !getenv("MST_CONV1_CHUNKED")) {
+    } else if ((e->sub == 2 || (e->sub == 1 && e->cfg.split_size % 2 == 0)) && !getenv("MST_CONV1_CHUNKED")) {
+      // band-resident kernel on 2 x 40 tiles; 16-mel sub-bands (pool height 1) take it with two 1 x 5 windows per lane
       using C = CC<1, 2>;
+      if (e->sub == 1) {
+        cp.pool_h = 1;
+        cp.tiles_r = e->cfg.split_size / 2;
+        cp.tiles_c = (L.W1 + 7) / 8;
+        cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+      }
+      const int g = std::min(grid, ns * cp.sets_per_band);
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {
