@@ -162,7 +162,8 @@ def test_second_config_detailed_and_odd_length():
     check_logmel(lm, omel.logmel(x))
 
 
-@pytest.mark.parametrize("n_fft,hop,n_mels", [(512, 128, 64), (1024, 256, 256), (2048, 441, 96)])
+@pytest.mark.parametrize("n_fft,hop,n_mels", [(512, 128, 64), (1024, 256, 256), (2048, 441, 96),
+                                              (1024, 256, 80), (1024, 256, 40), (2048, 512, 128), (2048, 512, 48)])
 def test_other_fft_sizes_vs_oracle(n_fft, hop, n_mels):
     x = cases.feature_case("synth1", 40000)[None]
     f, lm = run(x, fe(n_fft=n_fft, hop_length=hop, n_mels=n_mels))
