@@ -159,3 +159,43 @@ def test_deferred_rows_need_a_feature_layout():
         feats, logmel = ext.features_and_logmel(stems)
         assert feats.shape == (1, 180)
         assert torch.equal(m(stems, deferred_features(180)[None].cuda()), m.forward_from_logmel(logmel, feats))
+
+
+def test_reference_amp_branch_runs_unchanged(tmp_path):
+    """src/train.py:246-296, the `--use_amp` branch (scaler is not None): forward and loss under torch.cuda.amp.autocast,
+    scaler.scale(loss).backward(), scaler.step, scaler.update -- restated on this package.  The hand-written conv trunk
+    keeps computing in fp32 (a superset of the reference's fp16 autocast convolutions); the FiLM MLP and the attention head
+    run under autocast as torch modules; the InfoNCE kernels take the half-precision embeddings."""
+    from mst_amd.data import FMABaselineDataset, baseline_collate_fn
+    from mst_amd.loss import InfoNCELoss
+    from mst_amd.model import MixingStyleEncoder
+    device = torch.device("cuda")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ds = FMABaselineDataset(separated_path=cases.write_toy_tracks(str(tmp_path)), clip_duration=0.25, sample_rate=44100,
+                            n_fft=1024, hop_length=256, n_mels=128, num_segments=2, min_audio_duration=25.0)
+    dl = DataLoader(ds, batch_size=5, shuffle=True, num_workers=2, collate_fn=baseline_collate_fn, pin_memory=False,
+                    prefetch_factor=2, persistent_workers=False, multiprocessing_context='fork')
+    model = MixingStyleEncoder(sample_rate=44100, n_fft=1024, hop_length=256, n_mels=128, split_size=20, overlap=10,
+                               channels=8, embed_dim=768, feature_dim=ds[0][1][0].shape[0]).to(device)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)
+    criterion = InfoNCELoss(temperature=0.1)
+    scaler = torch.cuda.amp.GradScaler()
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    model.train()
+    for batch_data in dl:
+        stems_dict, mixing_features, song_labels, track_dirs = batch_data
+        stems_dict = {k: v.to(device) for k, v in stems_dict.items()}
+        mixing_features = mixing_features.to(device)
+        song_labels = song_labels.to(device)
+        optimizer.zero_grad()
+        with torch.cuda.amp.autocast():
+            embeddings = model(stems_dict, mixing_features)
+            loss_contrastive = criterion(embeddings, song_labels)
+            loss = loss_contrastive
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+        assert np.isfinite(loss.detach().item()) and embeddings.shape == (10, 768)
+    moved = [k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])]
+    assert len(moved) > 0.9 * len(before) and len(model._warned) == 0
