@@ -1069,7 +1069,8 @@ struct mst_plan {
   LaneBand* d_lanebands = nullptr;
   // sliding-window kernel (melfeat_v2.inc): packed-FFT twiddles and the segment form of the sparse mel table
   bool v2_ok = false;
-  int v2_nslot = 0, v2_glen[3] = {0, 0, 0}, v2_goff[3] = {0, 0, 0}, v2_segw_count = 0, v2_wps = 3;
+  int v2_nslot = 0, v2_glen[kV2Slots] = {0}, v2_goff[kV2Slots] = {0}, v2_segw_count = 0, v2_wps = 3, v2_maxcnt = 1;
+  int2* d_v2_bandtab = nullptr;
   // n_fft 2048 / hop 512 variant (melfeat_v2_2048.inc): W_2048 combine twiddles and the piece form of the mel table
   bool v4_ok = false;
   int v4_nslot = 0, v4_glen[4] = {0, 0, 0, 0}, v4_goff[4] = {0, 0, 0, 0}, v4_segw_count = 0, v4_maxcnt = 0;
@@ -1227,68 +1228,61 @@ int v4_runs(int F) {
   return (F + fpr - 1) / fpr;
 }
 
-// Segment form of the triangular filterbank for melfeat_v2_kernel.  Every bin k feeds at most two ADJACENT bands:
-// the falling edge of band s-1 and the rising edge of band s, where s = seg(k) numbers the interval between two
-// consecutive band centres.  Returns false (kernel not applicable) unless the table has exactly that structure.
+// Piece form of the triangular filterbank for melfeat_v2_kernel (n_fft 1024).  Every bin k feeds at most two ADJACENT
+// bands: the falling edge of band s-1 and the rising edge of band s, where s = seg(k) numbers the interval between two
+// consecutive band centres.  Segments are cut into pieces of at most 16 bins (an empty segment is one empty piece, so
+// that piece index == segment index whenever no segment is longer than 16 bins -- 128 mels: the kernel's fast path),
+// pieces are dealt to (slot, lane) by length, and every band gets the piece ranges of its rising segment (b) and of its
+// falling segment (b + 1).  Returns false (kernel not applicable) unless the table has exactly that structure.
 bool v2_build_segments(mst_plan* p, const float* fb, std::vector<float2>& segw, std::vector<int>& segstart,
-                       std::vector<int>& segid) {
+                       std::vector<int>& segid, std::vector<int2>& bandtab) {
   const int M = p->n_mels, n_bins = p->n_fft / 2 + 1;
-  if (p->n_fft != 1024 || M > 128) return false;
-  std::vector<int> peak(M, -1);
-  for (int m = 0; m < M; ++m) {
-    float best = 0.f;
-    for (int k = 0; k < n_bins; ++k)
-      if (fb[(size_t)k * M + m] > best) best = fb[(size_t)k * M + m], peak[m] = k;
-  }
-  std::vector<int> seg(n_bins, 0);
-  std::vector<float> wl(n_bins, 0.f), wh(n_bins, 0.f);
-  int prev = 0;
-  for (int k = 0; k < n_bins; ++k) {
-    int b0 = -1, b1 = -1, cnt = 0;
-    for (int m = 0; m < M; ++m)
-      if (fb[(size_t)k * M + m] != 0.0f) {
-        if (cnt == 0) b0 = m;
-        b1 = m;
-        ++cnt;
-      }
-    if (cnt > 2 || (cnt == 2 && b1 != b0 + 1)) return false;
-    int s = prev;
-    if (cnt == 2) {
-      s = b1, wl[k] = fb[(size_t)k * M + b0], wh[k] = fb[(size_t)k * M + b1];
-    } else if (cnt == 1) {
-      if (k <= peak[b0]) s = b0, wh[k] = fb[(size_t)k * M + b0];
-      else s = b0 + 1, wl[k] = fb[(size_t)k * M + b0];
-    }
-    if (s < prev) return false;   // segments must be contiguous bin ranges
-    seg[k] = prev = s;
-  }
+  if (p->n_fft != 1024 || M > 256) return false;
+  std::vector<int> seg;
+  std::vector<float> wl, wh;
+  if (!segment_bins(fb, n_bins, M, seg, wl, wh)) return false;
   const int nseg = M + 1;
   std::vector<int> start(nseg, 0), len(nseg, 0);
   for (int k = n_bins - 1; k >= 0; --k) start[seg[k]] = k, ++len[seg[k]];
-  std::vector<int> order(nseg);
-  for (int i = 0; i < nseg; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len[a] > len[b]; });
-  p->v2_nslot = (nseg + 63) / 64;
-  if (p->v2_nslot > 3) return false;
+  struct Piece { int start, len; };
+  std::vector<Piece> pieces;
+  std::vector<int> first(nseg, 0), cnt(nseg, 0);
+  p->v2_maxcnt = 1;
+  for (int sg = 0; sg < nseg; ++sg) {
+    first[sg] = (int)pieces.size();
+    if (len[sg] == 0) pieces.push_back({0, 0}), cnt[sg] = 1;
+    for (int o = 0; o < len[sg]; o += 16) pieces.push_back({start[sg] + o, std::min(16, len[sg] - o)}), ++cnt[sg];
+    p->v2_maxcnt = std::max(p->v2_maxcnt, cnt[sg]);
+  }
+  const int np = (int)pieces.size();
+  if (np > v2::kExDump) return false;
+  std::vector<int> order(np);
+  for (int i = 0; i < np; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return pieces[a].len > pieces[b].len; });
+  p->v2_nslot = (np + 63) / 64;
+  if (p->v2_nslot > kV2Slots || (M <= 128 && p->v2_nslot > 3)) return false;
   segstart.assign((size_t)p->v2_nslot * 64, 0);
-  segid.assign((size_t)p->v2_nslot * 64, 134);   // 134: dump slot of the in-scratch exchange arrays
+  segid.assign((size_t)p->v2_nslot * 64, v2::kExDump);
   int off = 0;
   for (int r = 0; r < p->v2_nslot; ++r) {
     int gl = 0;
-    for (int lane = 0; lane < 64 && r * 64 + lane < nseg; ++lane) gl = std::max(gl, len[order[r * 64 + lane]]);
-    if (gl > 16) return false;   // the walk may read 16 zeroed entries past bin 512
+    for (int lane = 0; lane < 64 && r * 64 + lane < np; ++lane) gl = std::max(gl, pieces[order[r * 64 + lane]].len);
     p->v2_glen[r] = gl, p->v2_goff[r] = off;
     segw.resize((size_t)(off + gl) * 64, make_float2(0.f, 0.f));
-    for (int lane = 0; lane < 64 && r * 64 + lane < nseg; ++lane) {
-      const int sg = order[r * 64 + lane];
-      segstart[(size_t)r * 64 + lane] = start[sg], segid[(size_t)r * 64 + lane] = sg;
-      for (int i = 0; i < len[sg]; ++i) segw[(size_t)(off + i) * 64 + lane] = make_float2(wl[start[sg] + i], wh[start[sg] + i]);
+    for (int lane = 0; lane < 64 && r * 64 + lane < np; ++lane) {
+      const int pc = order[r * 64 + lane];
+      segstart[(size_t)r * 64 + lane] = pieces[pc].start, segid[(size_t)r * 64 + lane] = pc;
+      for (int i = 0; i < pieces[pc].len; ++i)
+        segw[(size_t)(off + i) * 64 + lane] = make_float2(wl[pieces[pc].start + i], wh[pieces[pc].start + i]);
     }
     off += gl;
   }
   if (segw.size() & 1) segw.push_back(make_float2(0.f, 0.f));
   if (segw.empty()) segw.resize(2, make_float2(0.f, 0.f));
   p->v2_segw_count = (int)segw.size();
+  bandtab.assign(256, make_int2(v2::kExDump, v2::kExDump));
+  for (int b = 0; b < M; ++b)
+    bandtab[(size_t)(b >> 6) * 64 + (b & 63)] = make_int2(first[b] | (cnt[b] << 16), first[b + 1] | (cnt[b + 1] << 16));
   return true;
 }
 
@@ -1369,16 +1363,18 @@ int mst_plan_create(mst_plan** out, int sample_rate, int n_fft, int hop, int n_m
   {   // sliding-window kernel tables (standard configuration only)
     std::vector<float2> segw, t2(mstpk::kTw2Rows * 64), t3(mstpk::kTw3Rows * 64);
     std::vector<int> segstart, segid;
+    std::vector<int2> bandtab;
     const char* w = getenv("MST_V2_WPS");
-    p->v2_wps = (w && atoi(w) == 2) ? 2 : 3;
-    p->v2_ok = n_fft == 1024 && hop == 256 && v2_build_segments(p, fb, segw, segstart, segid);
+    p->v2_wps = ((w && atoi(w) == 2) || n_mels > 128) ? 2 : 3;   // 4 bands per lane need the 256-register build
+    p->v2_ok = n_fft == 1024 && hop == 256 && v2_build_segments(p, fb, segw, segstart, segid, bandtab);
     if (p->v2_ok) {
       mstpk::fill_twiddles_host(t2.data(), t3.data());
       int rc2;
       if ((rc2 = mst::upload(&p->d_v2_tw2, t2.data(), t2.size())) || (rc2 = mst::upload(&p->d_v2_tw3, t3.data(), t3.size())) ||
           (rc2 = mst::upload(&p->d_v2_segw, segw.data(), segw.size())) ||
           (rc2 = mst::upload(&p->d_v2_segstart, segstart.data(), segstart.size())) ||
-          (rc2 = mst::upload(&p->d_v2_segid, segid.data(), segid.size()))) {
+          (rc2 = mst::upload(&p->d_v2_segid, segid.data(), segid.size())) ||
+          (rc2 = mst::upload(&p->d_v2_bandtab, bandtab.data(), bandtab.size()))) {
         mst_plan_destroy(p);
         return rc2;
       }
@@ -1426,7 +1422,7 @@ void mst_plan_destroy(mst_plan* p) {
   (void)hipFree(p->d_window), (void)hipFree(p->d_tw), (void)hipFree(p->d_tw2), (void)hipFree(p->d_post), (void)hipFree(p->d_melw),
       (void)hipFree(p->d_lanebands);
   (void)hipFree(p->d_v2_tw2), (void)hipFree(p->d_v2_tw3), (void)hipFree(p->d_v2_segw), (void)hipFree(p->d_v2_segstart),
-      (void)hipFree(p->d_v2_segid);
+      (void)hipFree(p->d_v2_segid), (void)hipFree(p->d_v2_bandtab);
   (void)hipFree(p->d_v4_tw4), (void)hipFree(p->d_v4_segw), (void)hipFree(p->d_v4_pstart), (void)hipFree(p->d_v4_pid),
       (void)hipFree(p->d_v4_bandtab);
   delete p;
@@ -1550,18 +1546,20 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     for (int i = 0; i < 4; ++i) k2.stem[i] = stems4[i];
     k2.clip_stride = clip_stride, k2.logmel = logmel, k2.partials = reinterpret_cast<float*>(workspace);
     k2.window = p->d_window, k2.tw2 = p->d_v2_tw2, k2.tw3 = p->d_v2_tw3, k2.segw = p->d_v2_segw;
-    k2.segstart = p->d_v2_segstart, k2.segid = p->d_v2_segid;
+    k2.segstart = p->d_v2_segstart, k2.segid = p->d_v2_segid, k2.bandtab = p->d_v2_bandtab, k2.maxcnt = p->v2_maxcnt;
     k2.B = B, k2.T = T, k2.F = F, k2.M = p->n_mels;
     k2.nslot = p->v2_nslot, k2.segw_count = p->v2_segw_count;
-    for (int r = 0; r < 3; ++r) k2.glen[r] = p->v2_glen[r], k2.goff[r] = p->v2_goff[r];
+    for (int r = 0; r < kV2Slots; ++r) k2.glen[r] = p->v2_glen[r], k2.goff[r] = p->v2_goff[r];
     k2.fpw = v2_fpw(p, F), k2.runs_per_clip = v2_runs(p, F), k2.pstride = pstride_of(p);
     kp.runs_per_clip = k2.runs_per_clip;   // the finalise kernel walks the same records
     const int wps = p->v2_wps;
+    const bool wide = p->n_mels > 128;   // 4 bands per lane, 4-frame blocks
     const size_t lds2 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows) * 64 + p->v2_segw_count + 4 * wps * mstpk::kScr) * sizeof(float2) +
-                        (size_t)(wps * (wps == 2 ? 8 : 4) * 4 * 128 + 1024) * sizeof(float);
+                        (size_t)(wps * (wide ? 4 : (wps == 2 ? 8 : 4)) * 4 * (wide ? 256 : 128) + 1024) * sizeof(float);
     MST_REQUIRE(lds2 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds2);
     const int grid2 = B * k2.runs_per_clip;
-    if (wps == 3) e = pcm16 ? launch_melfeat_v2<short, 3>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 3>(k2, grid2, lds2, st);
+    if (wide) e = pcm16 ? launch_melfeat_v2<short, 2, 4>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 2, 4>(k2, grid2, lds2, st);
+    else if (wps == 3) e = pcm16 ? launch_melfeat_v2<short, 3>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 3>(k2, grid2, lds2, st);
     else e = pcm16 ? launch_melfeat_v2<short, 2>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 2>(k2, grid2, lds2, st);
   } else {
   const int grid = B * kp.runs_per_clip;
