@@ -962,21 +962,29 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
         ac.x *= p.f16_winv[cur.band * C::COUT + ch];  // undo the weight pre-scale
 #pragma unroll
         for (int wv = 0; wv < C::WPG; ++wv) {
-          float m = 0.f;
-#pragma unroll
-          for (int pos = 0; pos < C::WIN; ++pos) {
-            const int e = wv * C::WIN + pos;
-            m = fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y));
-          }
           const int pc = 4 * C::WPG * cur.tc + C::WPG * g + wv;
-          if (pc < p.out_cols) {
-            if (p.out) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
-            if (out_hi) {  // conv2's split-precision input: [clip][band][row][col][32 ch] f16, hi and lo, range-scaled
-              const size_t o = ((((size_t)cur.clip * p.nsub + cur.band) * p.out_rows + cur.tr) * p.out_cols + pc) * 32 + ch;
-              const float ms = m * f16s;
-              const _Float16 h = (_Float16)ms;
-              out_hi[o] = h;
-              if (TERMS == 3) out_lo[o] = (_Float16)(ms - (float)h);
+          const int nh = (SUB == 2 && p.pool_h == 1) ? 2 : 1;   // pool height 1: two 1 x 5 windows (tile rows 0 and 1) per lane
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr) {
+            if (hr < nh) {
+              float m = 0.f;
+#pragma unroll
+              for (int pos = 0; pos < C::WIN; ++pos) {
+                const int e = wv * C::WIN + pos;
+                const bool mine = nh == 1 || pos / 5 == hr;
+                m = mine ? fmaxf(m, fmaf(acc[e >> 2][n][e & 3], ac.x, ac.y)) : m;
+              }
+              const int orow_i = nh == 1 ? cur.tr : 2 * cur.tr + hr;   // output row
+              if (pc < p.out_cols && orow_i < p.out_rows) {
+                if (p.out) orow[(size_t)ch * p.out_rows * p.out_cols + (size_t)(orow_i - cur.tr) * p.out_cols + pc] = m;
+                if (out_hi) {  // conv2's split-precision input: [clip][band][row][col][32 ch] f16, hi and lo, range-scaled
+                  const size_t o = ((((size_t)cur.clip * p.nsub + cur.band) * p.out_rows + orow_i) * p.out_cols + pc) * 32 + ch;
+                  const float ms = m * f16s;
+                  const _Float16 h = (_Float16)ms;
+                  out_hi[o] = h;
+                  if (TERMS == 3) out_lo[o] = (_Float16)(ms - (float)h);
+                }
+              }
             }
           }
         }
@@ -989,8 +997,8 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 // OPT-IN conv2 on the f16 matrix cores, 3-term split precision (mst_encoder_set_precision(enc, 2)).
 // Input: conv1's pooled activations as f16 hi/lo, channel-minor.  A k-step is 4 taps x 8 input channels; the 32
 // input channels are processed in 4 chunks of 8 (13 k-steps each; the chunk's 104 KB of hi/lo weight fragments are
-// shared by the 8 waves, every wave has a private 14x14-position patch).  Activations above the f16 range (65504)
-// would saturate: the Python wrapper checks max(pool1) once before enabling this mode.
+// shared by the 8 waves, every wave has a private 14x14-position patch).  The input arrives range-scaled per
+// (clip, band) by f16_scale_kernel's power of two, undone in the epilogue: no activation magnitude saturates f16.
 // ------------------------------------------------------------------------------------------
 template <int TERMS>
 __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ in_hi,
@@ -2353,8 +2361,8 @@ void mst_encoder_destroy(mst_encoder* e) {
 
 int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
   MST_REQUIRE(e, "mst_encoder_set_precision: NULL encoder");
-  MST_REQUIRE(conv1_f16x3 == 0 || (conv1_f16x3 >= 1 && conv1_f16x3 <= 3 && e->sub == 2),
-              "mst_encoder_set_precision: the f16 modes (1, 2, 3) need the default 20-mel sub-bands (pool height 2)");
+  MST_REQUIRE(conv1_f16x3 == 0 || (conv1_f16x3 >= 1 && conv1_f16x3 <= 3 && (e->sub == 2 || (e->sub == 1 && e->cfg.split_size % 2 == 0))),
+              "mst_encoder_set_precision: the f16 modes (1, 2, 3) need 2-row conv1 tiles (20-mel sub-bands, or an even split_size below 20)");
   e->conv1_f16x3 = conv1_f16x3;
   return MST_OK;
 }
@@ -2409,8 +2417,15 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     const int g = std::min(grid, ns * cp.sets_per_band);
     hipError_t err;
-    if (e->sub == 2 && e->conv1_f16x3) {
+    if (e->conv1_f16x3) {   // (set_precision admits the f16 modes only for geometries that fit the 2 x 40 tiles)
       using C = CC<1, 2>;
+      if (e->sub == 1) {   // 16-mel sub-bands: pool height 1 on the same tiles
+        cp.pool_h = 1;
+        cp.tiles_r = e->cfg.split_size / 2;
+        cp.tiles_c = (L.W1 + 7) / 8;
+        cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+      }
+      const int g = std::min(grid, ns * cp.sets_per_band);
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
       static unsigned long long attr16 = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr16)) {

@@ -180,6 +180,33 @@ def test_conv_f16x3_split_precision_meets_the_fp32_bar(tag, T, mode):
     assert d_pool < 2e-6 and d_pin < 1e-5 and d_emb < 1e-5
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-all", "f16"])
+def test_conv_f16_modes_on_16_mel_sub_bands(mode):
+    """scripts/train_baseline.sh geometry (80 mels, 16/8 sub-bands, pool height 1): the split-precision modes sit on the
+    exact-fp32 kernels' result, the plain f16 mode on the oracle evaluated with f16-rounded conv operands."""
+    cfg = cases.CFG_BASELINE_SH
+    model, sd = build_model(cfg)
+    x = torch.stack([cases.synth_clip(c, 66150) for c in (0, 1)], 0)
+    with torch.no_grad():
+        stems = omel.tensor_to_stems_dict(x.cuda())
+        from mst_amd.mixing_utils import MixingFeatureExtractor
+        feats, lm = MixingFeatureExtractor(cfg["sample_rate"], cfg["n_fft"], cfg["hop_length"], cfg["n_mels"]).features_and_logmel(stems)
+        e32, t32 = model.hip_encoder().forward(lm, feats, taps=True)
+        model.conv1_precision = mode
+        e16, t16 = model.hip_encoder().forward(lm, feats, taps=True)
+        model.conv1_precision = "fp32"
+    assert t16["pool1"].shape == t32["pool1"].shape and torch.isfinite(e16).all()
+    if mode == "f16":
+        want = oenc.encoder_from_logmel(sd, lm.cpu(), feats.cpu(), cfg["split_size"], cfg["overlap"], f16_operands=True)
+        close(e16.cpu(), want)
+        return
+    d_pool = (t16["pool1"] - t32["pool1"]).abs().max().item() / t32["pool1"].abs().max().item()
+    d_pin = (t16["pool_in"] - t32["pool_in"]).abs().max().item() / t32["pool_in"].abs().max().item()
+    d_emb = (e16 - e32).abs().max().item() / e32.abs().max().item()
+    print(f"{mode} vs exact fp32 (16-mel sub-bands): pool1 {d_pool:.2e}, pool_in {d_pin:.2e}, embedding {d_emb:.2e}")
+    assert d_pool < 2e-6 and d_pin < 1e-5 and d_emb < 1e-5
+
+
 @pytest.mark.parametrize("gain", [1.0, 3.0e3, 3.0e5, 1.0e-4])
 def test_conv_f16x3_is_range_safe_for_any_activation_magnitude(gain):
     """The f16 split-precision modes scale conv2's f16 input per (clip, band) by a power of two derived on the device
