@@ -170,6 +170,20 @@ int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int f
                               float* emb, const mst_encoder_train_taps* taps, void* workspace,
                               size_t workspace_bytes, void* stream);
 
+/* Operand precision of the TRAINING kernels (all six entry points below and mst_encoder_forward_train).
+ * 0 (default): exact fp32 MFMA.  1: float16 operands, fp32 accumulation -- the arithmetic of the reference's `--use_amp`
+ * step (autocast + GradScaler, src/train.py:251-262, src/params.py:71; BASELINE configs[4]): both operands of every
+ * convolution-shaped product are rounded to f16 (forward y = conv(f16 x, f16 w); input gradient conv^T(f16 dy, f16 w);
+ * weight gradient corr(f16 x, f16 dy)); BatchNorm statistics, FiLM, pooling, their backward, all reductions and the master
+ * weights stay fp32.  Every rounded tensor is first multiplied by an exact power of two chosen on the device (weights per
+ * output channel; pool1 per band from a bound on its values; the gradients by one factor per backward pass from
+ * max |d pool_in| -- the internal equivalent of the reference's loss scale) and the factor is divided out in fp32, so neither
+ * f16's ceiling nor its subnormals are reached; no host synchronisation.  Needs 20-mel sub-bands.
+ * In mode 1 the `dy` of mst_encoder_train_backward_apply(layer 2) and the `dy2` of mst_encoder_train_conv2_dgrad are a
+ * float16 buffer [n_sub][B][H1][W1][64] (channel-minor; pass it through), and d pool_in must be contiguous.
+ * Call before mst_encoder_train_workspace_bytes and mst_encoder_update_trunk_params.                              */
+int mst_encoder_set_train_precision(mst_encoder* enc, int f16_operands);
+
 /* Refresh the convolution / BatchNorm parameters of the TRAINING kernels from device tensors (concatenated over the
  * sub-bands, reference state_dict shapes) -- once per optimizer step; re-swizzles the MFMA weight fragments on the
  * device.  The eval-mode constants (folded running statistics, f16 fragments) are NOT refreshed: create a new

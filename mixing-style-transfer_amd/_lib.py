@@ -74,6 +74,7 @@ SYMBOLS = {
     "mst_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EncoderConfig), C.POINTER(EncoderWeights)]),
     "mst_encoder_destroy": (None, [C.c_void_p]),
     "mst_encoder_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "mst_encoder_set_train_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "mst_encoder_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.POINTER(EncoderTaps), C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -755,12 +755,14 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   if ((threadIdx.x & 63) == 0) atomicMax(out + blockIdx.y, __float_as_uint(m));
 }
 
+// bias / gain: the training forward's affine acts on (acc + bias) and Dropout rescales the pooled value by `gain`
 __global__ __launch_bounds__(64) void f16_scale_kernel(const float2* __restrict__ aff1, const float* __restrict__ w1norm,
-                                                        const unsigned* __restrict__ xmax_bits, float* scale, int nsub) {
+                                                        const unsigned* __restrict__ xmax_bits, float* scale, int nsub,
+                                                        const float* __restrict__ bias = nullptr, float gain = 1.0f) {
   const int clip = blockIdx.x / nsub, band = blockIdx.x % nsub, c = threadIdx.x & 31;
   const float xmax = __uint_as_float(xmax_bits[clip]);
   const float2 a = aff1[((size_t)clip * nsub + band) * 32 + c];
-  float bound = fmaf(fabsf(a.x) * w1norm[band * 32 + c], xmax, fabsf(a.y));
+  float bound = fmaf(fabsf(a.x), fmaf(w1norm[band * 32 + c], xmax, bias ? fabsf(bias[band * 32 + c]) : 0.f), fabsf(a.y)) * gain;
   bound = mst::wave_max(bound);
   if (threadIdx.x == 0) {
     int k = 0;
@@ -777,6 +779,7 @@ __global__ __launch_bounds__(64) void f16_scale_kernel(const float2* __restrict_
 }
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ _Float16 to_f16_sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
 // weight pre-scale of the f16 fragments: an exact power of two per (band, output channel), chosen on the host so that the
 // filter's largest |w| lands in [2^13, 2^14) -- wl = w - wh stays a normal f16 whatever the weights' magnitude -- and
 // folded back per channel in the epilogue (ConvParams::f16_winv)
@@ -790,7 +793,9 @@ constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
 
 // TERMS = 3: split precision (fp32-equivalent, see above).  TERMS = 1: plain f16 operands (`x ~ xh`, `w ~ wh`), fp32
 // accumulate -- the arithmetic of the reference's `--use_amp` autocast convolutions (src/train.py:251-253), opt-in.
-template <int SUB, int TERMS>
+// MODE 1 (training forward, TERMS = 1): raw convolution output + bias in accumulator order and the batch-statistics sums,
+// exactly as conv1_resident_kernel<SUB, 1> leaves them.
+template <int SUB, int TERMS, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16,
                                                                   _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo) {
   using C = CC<1, SUB>;
@@ -863,6 +868,9 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
   };
 
   f32x4 acc[MT][NT];
+  double st[NT][2];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) st[n][0] = st[n][1] = 0.0;
   int cur_band = -1;
   Tile cur{}, nxt = decode(s_begin);
   prefetch_setup(nxt);
@@ -872,6 +880,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
   for (int s = s_begin; s < s_end; ++s) {
     cur = nxt;
     if (cur.band != cur_band) {
+      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
       __syncthreads();
       const h16x8* src = wfrag16 + (size_t)cur.band * WVEC;
       for (int k = tid; k < WVEC; k += kConvThreads) wres[k] = src[k];
@@ -949,7 +958,29 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
         __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
       }
     }
-    {
+    if constexpr (MODE == 1) {
+      const int j = lane & 15, g = lane >> 4;
+      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) *
+                               (size_t)(NT * 64 * 4 * MT);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float b = p.bias[cur.band * C::COUT + n * 16 + j];
+        const float wi = p.f16_winv[cur.band * C::COUT + n * 16 + j];   // undo the weight pre-scale (exact power of two)
+        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = acc[t][n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaf(v[r], wi, b);
+            const int e = 4 * t + r, wv = e / C::WIN, pos = e % C::WIN;
+            const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
+            if (col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
+          }
+          dst[t] = v;
+        }
+      }
+    } else {
       const int j = lane & 15, g = lane >> 4;
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
       float* orow = p.out + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT * p.out_rows * p.out_cols +
@@ -991,6 +1022,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
       }
     }
   }
+  if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1000,7 +1032,10 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 // shared by the 8 waves, every wave has a private 14x14-position patch).  The input arrives range-scaled per
 // (clip, band) by f16_scale_kernel's power of two, undone in the epilogue: no activation magnitude saturates f16.
 // ------------------------------------------------------------------------------------------
-template <int TERMS>
+// MODE 1 (training forward, TERMS = 1): raw output + bias in the 8 x 8-tile accumulator order and the batch-statistics
+// sums over the valid positions, as conv_kernel<2, 2, 1> leaves them (tiles past the last row are computed, not stored
+// in the sums: f16 MFMAs are cheap enough that the 2-row strip kernel of the fp32 path is not needed).
+template <int TERMS, int MODE = 0>
 __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ in_hi,
                                                                   const h16x8* __restrict__ in_lo,
                                                                   const h16x8* __restrict__ wfrag16) {
@@ -1072,6 +1107,10 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
   };
 
   f32x4 acc[MT][NT];
+  double st[NT][2];
+  int st_band = -1;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) st[n][0] = st[n][1] = 0.0;
   Tile cur{}, nxt = decode(0);
   if (nq > 0) prefetch(0, nxt);
   for (int q = 0; q < nq; ++q) {
@@ -1121,7 +1160,34 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
           acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
         }
     }
-    if (chunk == NCH - 1 && cur.valid) {
+    if (MODE == 1 && chunk == NCH - 1 && cur.valid) {
+      const int j = lane & 15, g = lane >> 4;
+      if (cur.band != st_band) {
+        if (st_band >= 0) flush_stats<NT, 64>(st, p.stats, st_band, lane);
+        st_band = cur.band;
+      }
+      const float inv_s = p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2 + 1] : 1.0f;
+      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) *
+                               (size_t)(NT * 64 * 4 * MT);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float b = p.bias[cur.band * 64 + n * 16 + j];
+        const float wi = inv_s * p.f16_winv[cur.band * 64 + n * 16 + j];   // input range scale and weight pre-scale, exact powers of two
+        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          f32x4 v = acc[t][n];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaf(v[r], wi, b);
+            const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
+            if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
+          }
+          dst[t] = v;
+        }
+      }
+    }
+    if (MODE == 0 && chunk == NCH - 1 && cur.valid) {
       const int j = lane & 15, g = lane >> 4;
       const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * 64;
       const float inv_s = p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2 + 1] : 1.0f;
@@ -1141,6 +1207,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
       }
     }
   }
+  if (MODE == 1 && st_band >= 0) flush_stats<NT, 64>(st, p.stats, st_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1341,6 +1408,10 @@ struct mst_encoder {
   // un-folded parameters for the training forward (batch-statistics BatchNorm)
   float *c1b = nullptr, *bn1w = nullptr, *bn1b = nullptr, *c2b = nullptr, *bn2w = nullptr, *bn2b = nullptr;
   float* w2dfrag = nullptr;   // conv2 input-gradient weight fragments [nsub][16][WBP] (refreshed by update_trunk_params)
+  // f16-operand training (mst_encoder_set_train_precision): fragments and pre-scales rebuilt on the device every step
+  int train_f16 = 0;
+  void* w2dfrag16 = nullptr;  // conv2 input-gradient fragments, hi only: [nsub][8 chunks][13 steps][2 nt][lane][8]
+  float *f16_wsc1 = nullptr, *f16_wsc2 = nullptr, *f16_wsc2d = nullptr, *f16_winv2d = nullptr;   // pre-scales 2^k and the dgrad inverse
 };
 
 namespace {
@@ -1442,6 +1513,10 @@ struct ApplyParams {
   float mask_scale;            // 1 / (1 - p)
   int B, nsub, tiles_r, tiles_c, out_rows, out_cols;
   long long units;   // B * nsub * tiles_r * tiles_c * NT * 64
+  // f16 training (layer 1): the pooled, Dropout-masked activation once more as f16, channel-minor
+  // [clip][band][row][col][32], times the (clip, band) range scale -- the operand layout of conv2_f16x3_kernel
+  _Float16* out_h16;
+  const float* f16_scale;   // [B][nsub][2] = (s, 1/s)
 };
 
 template <int LAYER, int SUB>
@@ -1482,7 +1557,11 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
       const int pc = 4 * C::WPG * tc + C::WPG * g + wv;
       if (pc < p.out_cols) {
         const size_t o = ((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + tr) * p.out_cols + pc;
-        p.out[o] = p.mask ? (p.mask[o] ? m * p.mask_scale : 0.f) : m;
+        const float v = p.mask ? (p.mask[o] ? m * p.mask_scale : 0.f) : m;
+        p.out[o] = v;
+        if (p.out_h16)
+          p.out_h16[((((size_t)clip * p.nsub + band) * p.out_rows + tr) * p.out_cols + pc) * 32 + ch] =
+              (_Float16)(v * p.f16_scale[((size_t)clip * p.nsub + band) * 2]);
       }
     }
   } else {
@@ -1518,6 +1597,10 @@ struct ApplyBwdParams {
   mst::DetAcc* sums;       // [nsub][COUT][2] (+=)  S1, S2
   float* dy;               // pass B: NCHW per band, or NULL: in place over yraw in accumulator order (dy_acc)
   float* dy_acc;
+  // f16 training: dpool is multiplied by in_scale[0] when it is read (layer 2: the backward pass's internal loss scale;
+  // NULL = 1), and layer 2's dy goes out as f16, channel-minor [band][clip][row][col][64] (conv2_dgrad_f16_kernel's operand)
+  const float* in_scale;
+  _Float16* dy_h16;
   int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
   double count;
   int chunks;              // pass A: blocks per (clip, band)
@@ -1545,6 +1628,7 @@ __device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v
 #pragma unroll
   for (int e = 0; e < NV; ++e) df[e] = 0.f;
   const float* dpb = p.dpool + clip * p.dp_clip + band * p.dp_band + ch * p.dp_ch;
+  const float sin = p.in_scale ? p.in_scale[0] : 1.0f;
   constexpr int NW = LAYER == 1 ? C::WPG : 1, WIN = LAYER == 1 ? C::WIN : NV;
 #pragma unroll
   for (int wv = 0; wv < NW; ++wv) {
@@ -1558,7 +1642,7 @@ __device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v
     int pr, pc;
     if constexpr (LAYER == 1) pr = tr, pc = 4 * C::WPG * tc + C::WPG * g + wv;
     else pr = 2 * tr + (g >> 1), pc = 2 * tc + (g & 1);
-    const float d = (am >= 0 && pr < p.dp_rows && pc < p.dp_cols) ? dpb[(size_t)pr * p.dp_cols + pc] : 0.f;
+    const float d = (am >= 0 && pr < p.dp_rows && pc < p.dp_cols) ? dpb[(size_t)pr * p.dp_cols + pc] * sin : 0.f;
 #pragma unroll
     for (int e = 0; e < WIN; ++e) df[wv * WIN + e] = (wv * WIN + e == am) ? d : 0.f;
   }
@@ -1661,6 +1745,18 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
         q[r] = (row < p.rows && col < p.cols) ? k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2) : 0.f;
       }
       dst[t] = q;
+    }
+  }
+  if (p.dy_h16 != nullptr) {
+    _Float16* dyh = p.dy_h16 + ((size_t)band * p.B + clip) * (size_t)p.rows * p.cols * C::COUT + ch;
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      int row, col;
+      unit_geometry<LAYER, SUB>(tr, tc, g, e, row, col);
+      if (row < p.rows && col < p.cols) {
+        const float zh = (v[e] - ms.x) * ms.y;
+        dyh[((size_t)row * p.cols + col) * C::COUT] = to_f16_sat(k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2));
+      }
     }
   }
   if (p.dy == nullptr) return;
@@ -2130,24 +2226,31 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   flush(cur_band, cur_chunk);
 }
 
-__global__ void sums_to_dbn_kernel(const mst::DetAcc* sums, float* dbn, int n) {
+#include "encoder_f16train.inc"
+
+// `unscale` (f16 training): (s, 1/s) of the backward pass's internal loss scale; the results are divided by s.  NULL: 1.
+__global__ void sums_to_dbn_kernel(const mst::DetAcc* sums, float* dbn, int n, const float* unscale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dbn[2 * i] = (float)mst::det_get(sums[2 * i + 1]), dbn[2 * i + 1] = (float)mst::det_get(sums[2 * i]);
+  const double u = unscale ? (double)unscale[1] : 1.0;
+  if (i < n) dbn[2 * i] = (float)(mst::det_get(sums[2 * i + 1]) * u), dbn[2 * i + 1] = (float)(mst::det_get(sums[2 * i]) * u);
 }
 
 // dfilm[clip][band][goff + ch] += gamma gradient, [boff + ch] += beta gradient of this layer (single writer per element)
-__global__ void dfilm_finish_kernel(const mst::DetAcc* acc, float* dfilm, int n192, int goff, int boff, int cout) {
+__global__ void dfilm_finish_kernel(const mst::DetAcc* acc, float* dfilm, int n192, int goff, int boff, int cout,
+                                    const float* unscale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over B * nsub * 2 * cout
   if (i >= n192 / 192 * 2 * cout) return;
   const int cb = i / (2 * cout), r = i % (2 * cout);
   const int slot = r < cout ? goff + r : boff + (r - cout);
-  dfilm[(size_t)cb * 192 + slot] += (float)mst::det_get(acc[(size_t)cb * 192 + slot]);
+  const double u = unscale ? (double)unscale[1] : 1.0;
+  dfilm[(size_t)cb * 192 + slot] += (float)(mst::det_get(acc[(size_t)cb * 192 + slot]) * u);
 }
 
 // float result of an order-independent accumulator array (weight gradients)
-__global__ void det_to_float_kernel(const mst::DetAcc* acc, float* out, long long n) {
+__global__ void det_to_float_kernel(const mst::DetAcc* acc, float* out, long long n, const float* unscale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = (float)mst::det_get(acc[i]);
+  const double u = unscale ? (double)unscale[1] : 1.0;
+  if (i < n) out[i] = (float)(mst::det_get(acc[i]) * u);
 }
 
 // conv weights [nsub][COUT][CIN][49] (device) -> MFMA B-fragment chunks, same layout as conv_fragments() builds on the host
@@ -2356,6 +2459,8 @@ void mst_encoder_destroy(mst_encoder* e) {
   (void)hipFree(e->w1frag16);
   (void)hipFree(e->w1norm), (void)hipFree(e->f16_winv1), (void)hipFree(e->f16_winv2);
   (void)hipFree(e->w2frag16);
+  (void)hipFree(e->w2dfrag16);
+  (void)hipFree(e->f16_wsc1), (void)hipFree(e->f16_wsc2), (void)hipFree(e->f16_wsc2d), (void)hipFree(e->f16_winv2d);
   delete e;
 }
 
@@ -2364,6 +2469,21 @@ int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
   MST_REQUIRE(conv1_f16x3 == 0 || (conv1_f16x3 >= 1 && conv1_f16x3 <= 3 && (e->sub == 2 || (e->sub == 1 && e->cfg.split_size % 2 == 0))),
               "mst_encoder_set_precision: the f16 modes (1, 2, 3) need 2-row conv1 tiles (20-mel sub-bands, or an even split_size below 20)");
   e->conv1_f16x3 = conv1_f16x3;
+  return MST_OK;
+}
+
+int mst_encoder_set_train_precision(mst_encoder* e, int f16_operands) {
+  MST_REQUIRE(e, "mst_encoder_set_train_precision: NULL encoder");
+  MST_REQUIRE(f16_operands == 0 || (f16_operands == 1 && e->sub == 2),
+              "mst_encoder_set_train_precision: the f16-operand training kernels need the default 20-mel sub-bands (pool height 2)");
+  if (f16_operands && !e->w2dfrag16) {
+    const int ns = e->cfg.n_subbands;
+    bool ok = hipMalloc(&e->w2dfrag16, (size_t)ns * 8 * kF16Steps * 2 * 64 * 8 * sizeof(_Float16)) == hipSuccess;
+    ok = ok && hipMalloc(&e->f16_wsc1, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_wsc2, (size_t)ns * 64 * 4) == hipSuccess;
+    ok = ok && hipMalloc(&e->f16_wsc2d, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_winv2d, (size_t)ns * 32 * 4) == hipSuccess;
+    if (!ok) return mst::fail(MST_ENOMEM, "mst_encoder_set_train_precision: out of device memory");
+  }
+  e->train_f16 = f16_operands;
   return MST_OK;
 }
 
@@ -2548,6 +2668,7 @@ namespace {
 struct TrainLayout {
   WsLayout base;
   size_t y1, y2, stats1, stats2, bn1, bn2, dfilm_acc, dw_acc, total;
+  size_t t_pool1_h16, t_f16scale, t_xmax, t_bscale;   // f16 training only (0 bytes otherwise)
   int tr1, tc1, tr2, tc2;
 };
 TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
@@ -2571,6 +2692,11 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   T.bn2 = take((size_t)ns * 64 * 8);
   T.dfilm_acc = take((size_t)B * ns * 192 * sizeof(mst::DetAcc));
   T.dw_acc = take((size_t)ns * 64 * 1568 * sizeof(mst::DetAcc));   // weight-gradient accumulators (conv2's size; conv1 reuses it)
+  const size_t f = e->train_f16 ? 1 : 0;
+  T.t_pool1_h16 = take(f * (size_t)B * ns * 32 * e->H1 * T.base.W1 * 2);   // pool1 as f16, channel-minor (conv2's operand)
+  T.t_f16scale = take(f * (size_t)B * ns * 2 * 4);
+  T.t_xmax = take(f * (size_t)B * 4);
+  T.t_bscale = take(f * 16);                                                // (s, 1/s) of the backward pass + the max |d pool_in| bits
   T.total = o;
   return T;
 }
@@ -2631,7 +2757,19 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.yraw = y1, cp.stats = stats1, cp.bias = e->c1b, cp.raw_rows = e->cfg.split_size, cp.raw_cols = frames;
     cp.acc_tr = T.tr1, cp.acc_tc = T.tc1;
     const int g = std::min(grid, ns * cp.sets_per_band);
-    if (e->sub == 2) {
+    if (e->train_f16) {   // f16 operands, fp32 accumulate (encoder_f16train.inc)
+      using C = CC<1, 2>;
+      constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (f16 train) attribute failed: %s", hipGetErrorString(err));
+      }
+      cp.f16_winv = e->f16_winv1;
+      hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp,
+                         reinterpret_cast<const h16x8*>(e->w1frag16), static_cast<_Float16*>(nullptr), static_cast<_Float16*>(nullptr));
+    } else if (e->sub == 2) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
@@ -2658,7 +2796,17 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
                   ns, 32, 0, 32};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
-                   B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64};
+                   B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr};
+    if (e->train_f16) {   // range scale of conv2's f16 operand: one power of two per band from a bound on the pooled values
+      unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);
+      float* fsc = reinterpret_cast<float*>(ws + T.t_f16scale);
+      MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
+      const long long npc = (long long)8 * e->cfg.n_mels * frames;
+      hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, npc, xmax);
+      hipLaunchKernelGGL(f16_scale_band_kernel, dim3(ns), dim3(64), 0, st, aff1, e->w1norm, xmax, e->c1b,
+                         (taps && taps->drop1_mask) ? taps->drop1_scale : 1.f, fsc, B, ns);
+      ap.out_h16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_h16), ap.f16_scale = fsc;
+    }
     if (e->sub == 2) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     else hipLaunchKernelGGL((apply_kernel<1, 1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
@@ -2679,7 +2827,24 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     cp.yraw = y2, cp.stats = stats2, cp.bias = e->c2b, cp.raw_rows = e->H1, cp.raw_cols = L.W1;
     cp.acc_tr = T.tr2, cp.acc_tc = T.tc2;
-    {
+    if (e->train_f16) {   // all tile rows on the f16 kernel (no strip: its padding costs less than a second launch)
+      cp.tiles_r = T.tr2;
+      cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+      const int g = std::min(grid, ns * cp.sets_per_band);
+      constexpr size_t lds = (size_t)(kF16Steps * 4 * 2 * 64 + kConvWaves * 2 * 14 * 14) * 16;
+      static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_set)) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<1, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 (f16 train) attribute failed: %s", hipGetErrorString(err));
+      }
+      cp.f16_scale = reinterpret_cast<const float*>(ws + T.t_f16scale);
+      cp.f16_winv = e->f16_winv2;
+      const h16x8* ih = reinterpret_cast<const h16x8*>(ws + T.t_pool1_h16);
+      hipLaunchKernelGGL((conv2_f16x3_kernel<1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, ih,
+                         reinterpret_cast<const h16x8*>(e->w2frag16));
+      MST_HIP_CHECK(hipGetLastError());
+    } else {
       const int g = std::min(grid, ns * cp.sets_per_band);
       using GEO = ConvGeom<2, 2>;
       const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
@@ -2692,7 +2857,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
       MST_HIP_CHECK(hipGetLastError());
     }
-    if (strip) {
+    if (strip && !e->train_f16) {
       ConvParams sp = cp;
       sp.row_off = 8 * (T.tr2 - 1);
       sp.tiles_r = (rows_last + 1) / 2, sp.tiles_c = (L.W1 + 39) / 40;
@@ -2765,6 +2930,25 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * sizeof(mst::DetAcc), st));
   p.dfilm_acc = reinterpret_cast<mst::DetAcc*>(ws + T.dfilm_acc);
   MST_HIP_CHECK(hipMemsetAsync(p.dfilm_acc, 0, (size_t)B * ns * 192 * sizeof(mst::DetAcc), st));
+  // f16 training: the backward pass runs under an internal power-of-two loss scale s chosen from max |d pool_in| (layer 2 =
+  // the start of the trunk's backward); d pool1 carries it to layer 1; every result that leaves the trunk is divided by s.
+  // In this mode `dy` of layer 2 is the f16 channel-minor operand of the f16 dgrad kernel, [n_sub][B][H1][W1][64] halves.
+  const float* unscale = nullptr;
+  if (e->train_f16) {
+    float* bs = reinterpret_cast<float*>(ws + T.t_bscale);
+    unscale = bs;
+    if (layer == 2) {
+      MST_REQUIRE(dp_ch == (long long)e->FD * L.W2 && dp_band == 64 * dp_ch && dp_clip == (long long)ns * dp_band,
+                  "mst_encoder_train_backward_apply: f16 training expects a contiguous d pool_in");
+      unsigned* bits = reinterpret_cast<unsigned*>(bs + 2);
+      MST_HIP_CHECK(hipMemsetAsync(bits, 0, sizeof(unsigned), st));
+      hipLaunchKernelGGL(absmax_kernel, dim3(256, 1), dim3(256), 0, st, dpool, (long long)B * dp_clip, bits);
+      hipLaunchKernelGGL(f16_bscale_kernel, dim3(1), dim3(1), 0, st, bits, bs);
+      p.in_scale = bs;
+      p.dy_h16 = reinterpret_cast<_Float16*>(dy);
+      p.dy = nullptr;
+    }
+  }
   if (layer == 1) {
     p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
     p.dy_acc = dy ? nullptr : reinterpret_cast<float*>(ws + T.y1);
@@ -2797,9 +2981,9 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   }
   MST_HIP_CHECK(hipGetLastError());
   // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
-  hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout);
+  hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout, unscale);
   hipLaunchKernelGGL(dfilm_finish_kernel, dim3((B * ns * 2 * cout + 255) / 256), dim3(256), 0, st, p.dfilm_acc, dfilm,
-                     B * ns * 192, p.goff, p.boff, cout);
+                     B * ns * 192, p.goff, p.boff, cout, unscale);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
@@ -2820,6 +3004,23 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
     const long long t3 = (long long)ns * 16 * 49 * 2 * 64;
     hipLaunchKernelGGL(dgrad_fragments_kernel, dim3((unsigned)((t3 + 255) / 256)), dim3(256), 0, st, conv2_w, e->w2dfrag, ns,
                        ConvGeom<3, 2>::WBP);
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  if (e->train_f16) {   // f16 fragments of the new weights: per-channel power-of-two pre-scale, then hi/lo (forward) / hi (dgrad)
+    hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 32), dim3(64), 0, st, conv1_w, 32, (long long)32 * 392, 392, 1, 0, 392,
+                       e->f16_wsc1, e->f16_winv1, e->w1norm);
+    hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 64), dim3(64), 0, st, conv2_w, 64, (long long)64 * 1568, 1568, 1, 0, 1568,
+                       e->f16_wsc2, e->f16_winv2, static_cast<float*>(nullptr));
+    hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 32), dim3(64), 0, st, conv2_w, 32, (long long)64 * 1568, 49, 64, 1568, 49,
+                       e->f16_wsc2d, e->f16_winv2d, static_cast<float*>(nullptr));
+    const long long n1 = (long long)ns * 1 * kF16Steps * 2 * 512, n2 = (long long)ns * 4 * kF16Steps * 4 * 512,
+                    n3 = (long long)ns * 8 * kF16Steps * 2 * 512;
+    hipLaunchKernelGGL(f16_fragments_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, conv1_w, e->f16_wsc1,
+                       reinterpret_cast<_Float16*>(e->w1frag16), ns, 32, 8, 2, 0);
+    hipLaunchKernelGGL(f16_fragments_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, conv2_w, e->f16_wsc2,
+                       reinterpret_cast<_Float16*>(e->w2frag16), ns, 64, 32, 2, 0);
+    hipLaunchKernelGGL(f16_fragments_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, conv2_w, e->f16_wsc2d,
+                       reinterpret_cast<_Float16*>(e->w2dfrag16), ns, 32, 64, 1, 1);
     MST_HIP_CHECK(hipGetLastError());
   }
   const struct { float* dst; const float* src; int n; } cp[] = {
@@ -2848,9 +3049,24 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
   const long long total = (long long)ns * B * T.tr1 * T.tc1;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv1_wgrad: too many tiles");
   const int g8 = (int)std::min<long long>(e->num_cus, total);
-  if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
+  const float* unscale = nullptr;
+  if (e->train_f16) {   // f16 operands, K = positions x 8 clips (encoder_f16train.inc)
+    unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
+    WgradF16Params fp{logmel, reinterpret_cast<const float*>(ws + T.y1), dwa, nullptr, B, ns, T.tr1, T.tc1,
+                      e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
+                      (long long)8 * e->cfg.n_mels * frames};
+    const long long items = (long long)ns * ((B + 7) / 8) * T.tr1 * T.tc1;
+    constexpr size_t lds = (size_t)(8 * 8 * 46 + 2 * 20 * 64) * 16;
+    static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+    if (mst::first_use_on_device(attr_set)) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 wgrad (f16) attribute failed: %s", hipGetErrorString(err));
+    }
+    hipLaunchKernelGGL((wgrad_f16_kernel<1>), dim3((int)std::min<long long>(e->num_cus, items)), dim3(kConvThreads), lds, st, fp);
+  } else if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
-  hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw);
+  hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw, unscale);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
@@ -2875,8 +3091,24 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   const long long total = (long long)ns * B * T.tr2 * T.tc2;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
   const int g = (int)std::min<long long>(e->num_cus & ~3, 4 * total);   // groups of 4 workgroups (one per input-channel chunk)
-  hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
-  hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw);
+  const float* unscale = nullptr;
+  if (e->train_f16) {
+    unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
+    WgradF16Params fp{pool1, reinterpret_cast<const float*>(ws + T.y2), dwa, reinterpret_cast<const float*>(ws + T.t_f16scale),
+                      B, ns, T.tr2, T.tc2, e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1};
+    const long long items = (long long)ns * ((B + 7) / 8) * T.tr2 * T.tc2;
+    constexpr size_t lds = (size_t)(8 * 14 * 14 + 4 * 16 * 64) * 16;
+    static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+    if (mst::first_use_on_device(attr_set)) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 wgrad (f16) attribute failed: %s", hipGetErrorString(err));
+    }
+    hipLaunchKernelGGL((wgrad_f16_kernel<2>), dim3((int)std::min<long long>(e->num_cus & ~3, 4 * items)), dim3(kConvThreads), lds, st, fp);
+  } else {
+    hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
+  }
+  hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw, unscale);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
@@ -2899,6 +3131,20 @@ int mst_encoder_train_conv2_dgrad(const mst_encoder* e, const float* dy2, int B,
   cp.raw_rows = H1, cp.raw_cols = W1, cp.mask = drop1_mask, cp.mask_scale = drop1_scale;
   MST_REQUIRE((long long)cp.in_bandoff * ns < (1LL << 31), "mst_encoder_train_conv2_dgrad: batch too large for 32-bit band offsets");
   const int g = std::min(e->num_cus, ns * cp.sets_per_band);
+  if (e->train_f16) {   // dy2 holds f16, channel-minor [n_sub][B][H1][W1][64] (mst_encoder_train_backward_apply in this mode)
+    constexpr size_t lds = (size_t)(kF16Steps * 2 * 64 + kConvWaves * 8 * 46) * 16;
+    static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
+    if (mst::first_use_on_device(attr_set)) {
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_f16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 dgrad (f16) attribute failed: %s", hipGetErrorString(err));
+    }
+    cp.f16_winv = e->f16_winv2d;
+    hipLaunchKernelGGL(conv2_dgrad_f16_kernel, dim3(g), dim3(kConvThreads), lds, st, cp, reinterpret_cast<const h16x8*>(dy2),
+                       reinterpret_cast<const h16x8*>(e->w2dfrag16));
+    MST_HIP_CHECK(hipGetLastError());
+    return MST_OK;
+  }
   using GEO = ConvGeom<3, 2>;
   const size_t lds = (size_t)(2 * GEO::WBP + kConvWaves * GEO::PATCH) * sizeof(float);
   static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device

@@ -259,6 +259,14 @@ class HipEncoder:
                        "mst_encoder_forward_train")
         return emb, out
 
+    def set_train_precision(self, f16: bool):
+        """Operand precision of the training kernels (`mst_encoder_set_train_precision`): False = exact fp32 MFMA, True =
+        float16 operands with fp32 accumulation (the reference's --use_amp arithmetic).  Takes effect with the next
+        `update_trunk_params` + `forward_train` pair."""
+        if bool(f16) != getattr(self, "train_f16", False):
+            _lib.check(_lib.lib().mst_encoder_set_train_precision(self._h, 1 if f16 else 0), "mst_encoder_set_train_precision")
+            self.train_f16 = bool(f16)
+
     def update_trunk_params(self, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b):
         """Refresh the training kernels' conv / BatchNorm parameters from device tensors stacked over the sub-bands."""
         ts = [t.detach().contiguous().float() for t in (c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)]
@@ -281,7 +289,9 @@ class HipEncoder:
         return dw
 
     def conv2_dgrad(self, dy2, B, frames, mask=None, drop_p=0.0):
-        """gradient of pool1 (B, n_sub, 32, H1, W1) from dy2 (n_sub, B, 64, H1, W1): `mst_encoder_train_conv2_dgrad`."""
+        """gradient of pool1 (B, n_sub, 32, H1, W1) from dy2 (n_sub, B, 64, H1, W1) -- f16 training: the float16
+        (n_sub, B, H1, W1, 64) tensor `backward_apply(2, ...)` returned: `mst_encoder_train_conv2_dgrad`."""
+        assert dy2.dtype == (torch.float16 if getattr(self, "train_f16", False) else torch.float32)
         L = _lib.lib()
         out = torch.empty(B, self.n_sub, 32, self.split // self.sub, frames // 5, device=dy2.device)
         with torch.cuda.device(dy2.device):
@@ -320,7 +330,10 @@ class HipEncoder:
             dpool = dpool.contiguous()
             W2 = W1 // 4
             st = (dpool.shape[1] * W2, 64 * self.freq_dim * W2, self.freq_dim * W2)
-            dy = torch.empty(self.n_sub, B, 64, self.split // self.sub, W1, device=dev)
+            if getattr(self, "train_f16", False):   # the f16 dgrad kernel's operand: channel-minor halves
+                dy = torch.empty(self.n_sub, B, self.split // self.sub, W1, 64, device=dev, dtype=torch.float16)
+            else:
+                dy = torch.empty(self.n_sub, B, 64, self.split // self.sub, W1, device=dev)
             dbn = torch.empty(self.n_sub, 64, 2, device=dev)
         need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
         with torch.cuda.device(dev):
@@ -412,6 +425,8 @@ class _HipTrunk(torch.autograd.Function):
         mark("apply_bwd2")
         gi, gw2, gb2 = [], [], []
         native_w2, native_d2 = not _CONV2_WGRAD_MIOPEN, not _CONV2_DGRAD_MIOPEN
+        if getattr(enc, "train_f16", False):   # the library A/B switches exist for the fp32 kernels only
+            native_w2 = native_d2 = True
         if not (native_w2 and native_d2):
             for i in range(ns):
                 a, b, c = bw(dy2[i], p1[:, i].contiguous(), c2w[i], [64], [1, 1], [3, 3], [1, 1], False, [0, 0], 1,
@@ -432,7 +447,7 @@ class _HipTrunk(torch.autograd.Function):
             if mask is not None:
                 dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
             mark("stack+mask")
-        if _CONV1_WGRAD_MIOPEN:   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (for A/B checks)
+        if _CONV1_WGRAD_MIOPEN and not getattr(enc, "train_f16", False):   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (A/B checks)
             dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
             mark("apply_bwd1")
             gw1, gb1 = [], []
@@ -473,6 +488,10 @@ class MixingStyleEncoder(nn.Module):
         # (see _HipTrunk; 52 ms vs 98 ms per 72-clip step); "torch" = everything on PyTorch-ROCm autograd
         # "hip-strict" = as "hip", but raise instead of warning when a call cannot take the hand-written trunk
         self.train_backend = "hip"
+        # operand precision of the hand-written training trunk: "fp32" (exact), "f16" (float16 operands, fp32 accumulation:
+        # the reference's --use_amp arithmetic, see include/mst.h mst_encoder_set_train_precision), or "auto" = f16 inside
+        # `torch.autocast(dtype=float16)` (what src/train.py:251 turns on), fp32 otherwise
+        self.train_precision = "auto"
         self._warned = set()
 
     def _params_version(self):
@@ -494,6 +513,19 @@ class MixingStyleEncoder(nn.Module):
         if self._hip_train is None:
             self._hip_train = HipEncoder(self, "fp32")
         enc = self._hip_train
+        if self.train_precision not in ("fp32", "f16", "auto"):
+            raise ValueError("train_precision must be 'fp32', 'f16' or 'auto'")
+        want_f16 = self.train_precision == "f16" or (
+            self.train_precision == "auto" and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16)
+        if want_f16 and enc.sub != 2:
+            why = f"split_size={ae.split_size}: the f16-operand training kernels cover 20-mel sub-bands; the trunk stays fp32"
+            if self.train_precision == "f16":
+                raise RuntimeError("MixingStyleEncoder.train_precision='f16': " + why)
+            if why not in self._warned:
+                self._warned.add(why)
+                warnings.warn("MixingStyleEncoder under autocast: " + why, RuntimeWarning, stacklevel=3)
+            want_f16 = False
+        enc.set_train_precision(want_f16)
         cn = ae.subnet_cnns
         st = lambda f: torch.stack([f(c) for c in cn])  # noqa: E731
         flat = fe.film_head(fe.feature_mlp(mixing_features))

@@ -27,9 +27,18 @@ def film_params(sd, feats: torch.Tensor) -> torch.Tensor:
     return F.linear(h, sd[p + "film_head.weight"], sd[p + "film_head.bias"])
 
 
+def round_f16_ideal(t: torch.Tensor) -> torch.Tensor:
+    """nearest-even rounding to 11 significant bits (float16's precision) with the exponent range of the input dtype"""
+    m, e = torch.frexp(t)                      # |m| in [0.5, 1)
+    return torch.ldexp(torch.round(m * 2048.0) / 2048.0, e)
+
+
 def _f16_operand(t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-    """value after a round trip through float16 (optionally pre-scaled by a power of two so small weights stay normal)"""
-    return (t * scale).to(torch.float16).to(torch.float32) / scale
+    """value after a round trip through float16.  The kernels multiply every operand by an exact power of two before the
+    conversion (weights per output channel, activations per band) so that neither float16's ceiling nor its subnormals
+    are reached: the round trip is a rounding to 11 significant bits, whatever the magnitude (`scale` is kept for callers
+    of the first version, which pre-scaled by a fixed 2^10)."""
+    return round_f16_ideal(t)
 
 
 def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int,

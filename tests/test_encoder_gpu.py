@@ -306,6 +306,122 @@ def test_train_mode_forward_batch_statistics(T, B):
     assert (emb - e_eval).abs().max().item() > 1e-3 * e_eval.abs().max().item()   # it is NOT the eval forward
 
 
+def _stacked_trunk_params(model):
+    cn = model.audio_encoder.subnet_cnns
+    st = lambda f: torch.stack([f(c) for c in cn]).detach()  # noqa: E731
+    return (st(lambda c: c.conv1.weight), st(lambda c: c.conv1.bias), st(lambda c: c.bn1.weight), st(lambda c: c.bn1.bias),
+            st(lambda c: c.conv2.weight), st(lambda c: c.conv2.bias), st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias))
+
+
+@pytest.mark.parametrize("T,B,gain", [(66150, 3, 1.0), (44100, 10, 3.0e3)])
+def test_f16_train_forward_matches_the_oracle_with_f16_operands(T, B, gain):
+    """f16-operand training forward (`mst_encoder_set_train_precision(enc, 1)`; BASELINE configs[4] / the reference's
+    --use_amp convolutions): conv inputs and weights rounded to float16, fp32 accumulation, train-mode BatchNorm -- against
+    the oracle evaluated with exactly those roundings; the weight fragments come from the per-step device rebuild.
+    gain 3e3 multiplies conv1's weights: BatchNorm(batch statistics) removes it again, so the activations stay O(1), but the
+    weights themselves (max ~1e2) and the bound that the per-band range scale is derived from grow with it."""
+    from oracle.train_f16 import round_f16_ideal  # noqa: F401  (the oracle's f16_operands path is the eval-tested one)
+    cfg = cases.CFG_DEFAULT
+    model, sd = build_model(cfg)
+    if gain != 1.0:
+        with torch.no_grad():
+            for c in model.audio_encoder.subnet_cnns:
+                c.conv1.weight.mul_(gain), c.conv1.bias.mul_(gain)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.1 * (c // 4)) for c in range(B)], 0)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(B, 64, generator=g) * 3.0
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        enc = model.hip_encoder()
+        e32, t32 = enc.forward_train(lm, feats.cuda())
+        enc.set_train_precision(True)
+        enc.update_trunk_params(*_stacked_trunk_params(model))
+        emb, t = enc.forward_train(lm, feats.cuda())
+        enc.set_train_precision(False)
+    torch.cuda.synchronize()
+    taps = {}
+    want = oenc.encoder_from_logmel(sd, lm.cpu(), feats, cfg["split_size"], cfg["overlap"], taps, f16_operands=True, bn_training=True)
+    ns = cases.n_subbands(cfg["n_mels"], cfg["split_size"], cfg["overlap"])
+    for i in (0, ns // 2, ns - 1):
+        for name in ("bn1", "bn2"):
+            mean, var = taps[f"{name}_{i}"]
+            got = t[name][i].cpu()
+            close(got[:, 0], mean, 1e-4)
+            close(1.0 / got[:, 1] ** 2 - 1e-5, var, 2e-4)
+        close(t["pool1"][:, i].cpu(), taps[f"pool1_{i}"])
+    close(t["pool_in"].cpu(), taps["pool_in"])
+    close(emb.cpu(), want)
+    d = (emb - e32).abs().max().item() / e32.abs().max().item()
+    print(f"f16-operand training forward vs exact fp32 training forward: embeddings {d:.2e} of max")
+    assert 1e-6 < d < 2e-2   # it IS the f16 arithmetic, and it is close to fp32
+
+
+@pytest.mark.parametrize("loss_gain", [1.0, 1.0e-6])
+def test_f16_training_gradients_match_autograd_with_the_same_operand_roundings(loss_gain):
+    """`train_precision="f16"`: loss, every parameter gradient and the running statistics against float64 autograd of the
+    same modules whose convolutions round BOTH operands of the forward product, of the input gradient and of the weight
+    gradient to float16 precision (oracle/train_f16.py) -- the arithmetic contract of the mode (include/mst.h).  The
+    internal power-of-two loss scale makes the result independent of the magnitude of the upstream gradient: with
+    loss_gain 1e-6 the unscaled d(conv output) values (~1e-9) would vanish in float16.  Criterion as for the fp32 trunk:
+    every tensor within 1e-2 norm-wise, at least 80 % within 1e-4 (near-tie max-pool decisions and float16 rounding
+    boundaries crossed by fp32-vs-float64 differences upstream perturb single sub-bands), worst deviation and its
+    distribution in the parity report.  Also reported: the distance of the f16 gradients from the exact-fp32 trunk's."""
+    import copy
+    from oracle.train_f16 import convert_convs
+    cfg = cases.CFG_DEFAULT
+    model, sd = build_model(cfg)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    exact = copy.deepcopy(model)
+    ref64 = convert_convs(copy.deepcopy(model).double())
+    for m_ in (model, exact, ref64):
+        m_.train()
+    model.train_backend, exact.train_backend, ref64.train_backend = "hip-strict", "hip-strict", "torch"
+    model.train_precision, exact.train_precision = "f16", "fp32"
+    B, T = 10, 44100    # two groups of 8 clips for the weight-gradient kernels, the second one ragged
+    x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.1 * (c // 4)) for c in range(B)], 0).cuda()
+    stems = omel.tensor_to_stems_dict(x)
+    g = torch.Generator().manual_seed(8)
+    feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
+    R = (torch.randn(B, cfg["embed_dim"], generator=g) * loss_gain).cuda()
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(stems)
+    la = (model.forward_from_logmel(lm, feats) * R).sum()
+    lb = (exact.forward_from_logmel(lm, feats) * R).sum()
+    lc = (ref64.forward_from_logmel(lm.double(), feats.double()) * R.double()).sum()
+    la.backward(), lb.backward(), lc.backward()
+    assert model._hip_train.train_f16 and not exact._hip_train.train_f16
+    close(la.item(), lc.item(), 1e-4)
+    errs = []
+    grads = dict(model.named_parameters())
+    for (n, pa), (_, pb), (_, pc) in zip(model.named_parameters(), exact.named_parameters(), ref64.named_parameters()):
+        assert pa.grad is not None and torch.isfinite(pa.grad).all(), n
+        den = pc.grad.abs().max().item()
+        if "subnet_cnns" in n and n.endswith(("conv1.bias", "conv2.bias")):
+            wmax = grads[n[:-4] + "weight"].grad.abs().max().item()
+            assert pa.grad.abs().max().item() < 1e-3 * wmax, n
+            continue
+        if den < 1e-9 * loss_gain * max(1.0, pc.abs().max().item()):
+            continue
+        errs.append((n, (pa.grad.double() - pc.grad).abs().max().item() / den, (pb.grad.double() - pc.grad).abs().max().item() / den))
+    e16 = np.array([a for _, a, _ in errs])
+    out = [(n, f"{a:.1e}") for n, a, _ in errs if a >= 1e-4]
+    far = np.array([b for _, _, b in errs])
+    print(f"f16 training, loss gain {loss_gain:g}: gradient error vs the float64 oracle with f16 operand roundings over {len(errs)} "
+          f"tensors: worst {e16.max():.2e}, median {np.median(e16):.2e}, outliers {out}; exact-fp32 trunk vs the same oracle "
+          f"(= how far f16 arithmetic is from fp32): median {np.median(far):.2e}, worst {far.max():.2e}")
+    parity.note(f"f16 train gradients vs float64 autograd with f16 operand roundings [loss gain {loss_gain:g}], norm-wise per tensor",
+                tensors=len(errs), hip_max=float(e16.max()), hip_p90=float(np.percentile(e16, 90)), hip_median=float(np.median(e16)),
+                hip_beyond_1e4=len(out), fp32_trunk_vs_f16_oracle_median=float(np.median(far)))
+    assert e16.max() < 1e-2 and len(out) <= 0.2 * len(errs), out
+    assert np.median(far) > 3.0 * np.median(e16)   # the oracle's roundings are the ones the kernels apply, not fp32's
+    for (n, ba), (_, bc) in zip(model.named_buffers(), ref64.named_buffers()):
+        if "running" in n:
+            close(ba.cpu(), bc.cpu(), 1e-4)
+
+
 def test_train_mode_backward_of_pool_relu_film_batchnorm():
     """`mst_encoder_train_backward_apply` (max-pool -> ReLU -> FiLM -> BatchNorm with batch statistics, both
     layers) against torch autograd through the oracle: gradient of the convolution outputs, of the FiLM parameters and
