@@ -48,6 +48,11 @@ def parse():
                     help="extra measurement, not the contract line: a full TRAINING step (stage A, encoder forward + backward "
                          "with train-mode BatchNorm and Dropout, InfoNCE forward + backward, AdamW) instead of the forward path")
     ap.add_argument("--train-backend", choices=["hip", "torch"], default="hip")
+    ap.add_argument("--train-precision", choices=["fp32", "f16", "amp"], default="fp32",
+                    help="--train only.  fp32: exact fp32 MFMA trunk.  f16: the hand-written trunk with float16 operands / fp32 "
+                         "accumulation (BASELINE configs[4]'s fp16), everything else fp32.  amp: the reference's --use_amp step "
+                         "(src/train.py:246-262): forward and loss under torch.autocast(float16), GradScaler; the trunk "
+                         "switches to its f16 kernels by itself, the torch backend runs MIOpen's half convolutions")
     ap.add_argument("--ingest", choices=["resident", "f32", "pcm16"], default="resident",
                     help="resident (default, the contract: inputs in HBM before timing) | f32 | pcm16: every step's batch "
                          "comes from pinned host memory over PCIe (double-buffered, overlapped); PCIe-inclusive rate")
@@ -267,16 +272,20 @@ def main():
     if a.train:   # training step: same data, same metric unit; reported with its own workload string
         model.train()
         model.train_backend = a.train_backend
+        model.train_precision = {"fp32": "fp32", "f16": "f16", "amp": "auto"}[a.train_precision]
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
         crit_t = InfoNCELoss(0.1, gather=world > 1)
+        amp = a.train_precision == "amp"
+        scaler = torch.amp.GradScaler("cuda") if amp else None
 
         def train_step():
             with torch.no_grad():
                 feats, logmel = fe.features_and_logmel(stems)
-            emb = model.forward_from_logmel(logmel, feats)
-            loss = crit_t(emb, labels)
+            with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+                emb = model.forward_from_logmel(logmel, feats)
+                loss = crit_t(emb, labels)
             opt.zero_grad(set_to_none=True)
-            loss.backward()
+            (scaler.scale(loss) if amp else loss).backward()
             if world > 1:   # data-parallel: sum the parameter gradients (see loss.InfoNCELoss) in ONE 13 MB all-reduce
                 gs = [prm.grad for prm in model.parameters() if prm.grad is not None]
                 flat = torch.cat([g_.reshape(-1) for g_ in gs])
@@ -285,7 +294,11 @@ def main():
                 for g_ in gs:
                     g_.copy_(flat[off:off + g_.numel()].view_as(g_))
                     off += g_.numel()
-            opt.step()
+            if amp:
+                scaler.step(opt)
+                scaler.update()
+            else:
+                opt.step()
             return loss
         for _ in range(max(a.warmup, 5)):
             train_step()
@@ -307,11 +320,14 @@ def main():
                 "unit": "triplets/s", "n_gpus": world, "world": world, "rccl_ranks_seen": ranks_seen, "steps": a.steps,
                 "warmup": max(a.warmup, 5),
                 "ms_per_step": round(t.item() / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"NOT THE CONTRACT LINE -- full TRAINING step ({a.train_backend} encoder backend): HIP stage A, "
+                "vs_baseline": None, "dtype": {"fp32": "f32", "f16": "f16 operands / f32 accumulate (conv trunk)",
+                                               "amp": "autocast f16 + GradScaler"}[a.train_precision], "data": "synthetic",
+                "config": {"workload": f"NOT THE CONTRACT LINE -- full TRAINING step ({a.train_backend} encoder backend, "
+                                       f"precision {a.train_precision}): HIP stage A, "
                                        "encoder forward + backward (train-mode BatchNorm, Dropout 0.3), InfoNCE forward + backward, "
                                        f"AdamW; {a.triplets} triplets = {B} clips of {a.seconds:.0f} s per GPU",
-                           "clips_per_gpu": B, "train_backend": a.train_backend, "loss": float(loss.detach()),
+                           "clips_per_gpu": B, "train_backend": a.train_backend, "train_precision": a.train_precision,
+                           "loss": float(loss.detach()),
                            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}}), flush=True)
         if world > 1:
             dist.destroy_process_group()

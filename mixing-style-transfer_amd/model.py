@@ -213,6 +213,7 @@ class HipEncoder:
         self.mode = modes[conv1_precision]
         _lib.check(_lib.lib().mst_encoder_set_precision(h, self.mode), "mst_encoder_set_precision")
         self._ws = None
+        self.train_f16 = False   # operand precision of the training kernels (set_train_precision)
         self.embed_dim = ae.attention_pooling.output_dim
         self.n_sub, self.split, self.freq_dim, self.overlap = ae.n_subbands, ae.split_size, ae.freq_dim, ae.overlap
         self.sub = max(1, ae.split_size // 10)   # pool height of the first max-pool

@@ -361,12 +361,17 @@ def test_f16_train_forward_matches_the_oracle_with_f16_operands(T, B, gain):
 def test_f16_training_gradients_match_autograd_with_the_same_operand_roundings(loss_gain):
     """`train_precision="f16"`: loss, every parameter gradient and the running statistics against float64 autograd of the
     same modules whose convolutions round BOTH operands of the forward product, of the input gradient and of the weight
-    gradient to float16 precision (oracle/train_f16.py) -- the arithmetic contract of the mode (include/mst.h).  The
-    internal power-of-two loss scale makes the result independent of the magnitude of the upstream gradient: with
-    loss_gain 1e-6 the unscaled d(conv output) values (~1e-9) would vanish in float16.  Criterion as for the fp32 trunk:
-    every tensor within 1e-2 norm-wise, at least 80 % within 1e-4 (near-tie max-pool decisions and float16 rounding
-    boundaries crossed by fp32-vs-float64 differences upstream perturb single sub-bands), worst deviation and its
-    distribution in the parity report.  Also reported: the distance of the f16 gradients from the exact-fp32 trunk's."""
+    gradient to float16 precision (oracle/train_f16.py) -- the arithmetic contract of the mode (include/mst.h).
+    The internal power-of-two loss scale makes the result independent of the magnitude of the upstream gradient: with
+    loss_gain 1e-6 the unscaled d(conv output) values (~1e-9) would vanish in float16.
+    Rounding to float16 makes the loss piecewise smooth: an evaluation that differs from float64 in the last fp32 bits
+    crosses a few rounding boundaries and max-pool ties, and each crossing moves one sub-band's gradients by 1e-3..1e-2
+    (batch of 10 one-second clips: a pooled plane has 16 entries per clip and channel).  That is a property of the
+    arithmetic, not of the kernels: the SAME oracle evaluated by PyTorch in fp32 deviates from its float64 evaluation in
+    the same way, largely in the same sub-bands.  Hence the criterion, relative to that fp32 evaluation: median error
+    below 1e-4, at least 60 % of the tensors within 2e-4, no more tensors beyond 1e-3 than PyTorch-fp32 has + 3, worst
+    deviation at most 1.25 x PyTorch-fp32's worst (or 5e-3).  The exact-fp32 trunk is 1.7e-2 (median) away from this
+    oracle, i.e. the test does tell f16 arithmetic from fp32 arithmetic.  Everything goes into the parity report."""
     import copy
     from oracle.train_f16 import convert_convs
     cfg = cases.CFG_DEFAULT
@@ -375,10 +380,11 @@ def test_f16_training_gradients_match_autograd_with_the_same_operand_roundings(l
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
     exact = copy.deepcopy(model)
+    ref32 = convert_convs(copy.deepcopy(model))
     ref64 = convert_convs(copy.deepcopy(model).double())
-    for m_ in (model, exact, ref64):
+    for m_ in (model, exact, ref32, ref64):
         m_.train()
-    model.train_backend, exact.train_backend, ref64.train_backend = "hip-strict", "hip-strict", "torch"
+    model.train_backend, exact.train_backend, ref32.train_backend, ref64.train_backend = "hip-strict", "hip-strict", "torch", "torch"
     model.train_precision, exact.train_precision = "f16", "fp32"
     B, T = 10, 44100    # two groups of 8 clips for the weight-gradient kernels, the second one ragged
     x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.1 * (c // 4)) for c in range(B)], 0).cuda()
@@ -390,13 +396,15 @@ def test_f16_training_gradients_match_autograd_with_the_same_operand_roundings(l
         lm = model.audio_encoder.mel_preprocessor(stems)
     la = (model.forward_from_logmel(lm, feats) * R).sum()
     lb = (exact.forward_from_logmel(lm, feats) * R).sum()
+    lt = (ref32.forward_from_logmel(lm, feats) * R).sum()
     lc = (ref64.forward_from_logmel(lm.double(), feats.double()) * R.double()).sum()
-    la.backward(), lb.backward(), lc.backward()
+    la.backward(), lb.backward(), lt.backward(), lc.backward()
     assert model._hip_train.train_f16 and not exact._hip_train.train_f16
     close(la.item(), lc.item(), 1e-4)
     errs = []
     grads = dict(model.named_parameters())
-    for (n, pa), (_, pb), (_, pc) in zip(model.named_parameters(), exact.named_parameters(), ref64.named_parameters()):
+    for (n, pa), (_, pb), (_, pt), (_, pc) in zip(model.named_parameters(), exact.named_parameters(), ref32.named_parameters(),
+                                                  ref64.named_parameters()):
         assert pa.grad is not None and torch.isfinite(pa.grad).all(), n
         den = pc.grad.abs().max().item()
         if "subnet_cnns" in n and n.endswith(("conv1.bias", "conv2.bias")):
@@ -405,18 +413,21 @@ def test_f16_training_gradients_match_autograd_with_the_same_operand_roundings(l
             continue
         if den < 1e-9 * loss_gain * max(1.0, pc.abs().max().item()):
             continue
-        errs.append((n, (pa.grad.double() - pc.grad).abs().max().item() / den, (pb.grad.double() - pc.grad).abs().max().item() / den))
-    e16 = np.array([a for _, a, _ in errs])
-    out = [(n, f"{a:.1e}") for n, a, _ in errs if a >= 1e-4]
-    far = np.array([b for _, _, b in errs])
+        rel = lambda q: (q.grad.double() - pc.grad).abs().max().item() / den  # noqa: E731
+        errs.append((n, rel(pa), rel(pb), rel(pt)))
+    e16, far, t32 = (np.array([e[k] for e in errs]) for k in (1, 2, 3))
+    out = [(n, f"{a:.1e}") for n, a, _, _ in errs if a >= 1e-3]
     print(f"f16 training, loss gain {loss_gain:g}: gradient error vs the float64 oracle with f16 operand roundings over {len(errs)} "
-          f"tensors: worst {e16.max():.2e}, median {np.median(e16):.2e}, outliers {out}; exact-fp32 trunk vs the same oracle "
-          f"(= how far f16 arithmetic is from fp32): median {np.median(far):.2e}, worst {far.max():.2e}")
+          f"tensors: worst {e16.max():.2e}, median {np.median(e16):.2e}, within 2e-4: {int((e16 < 2e-4).sum())}, beyond 1e-3: {out}; "
+          f"the same oracle in PyTorch fp32: worst {t32.max():.2e}, median {np.median(t32):.2e}, beyond 1e-3: {int((t32 >= 1e-3).sum())}; "
+          f"exact-fp32 trunk vs the oracle (= how far f16 arithmetic is from fp32): median {np.median(far):.2e}, worst {far.max():.2e}")
     parity.note(f"f16 train gradients vs float64 autograd with f16 operand roundings [loss gain {loss_gain:g}], norm-wise per tensor",
                 tensors=len(errs), hip_max=float(e16.max()), hip_p90=float(np.percentile(e16, 90)), hip_median=float(np.median(e16)),
-                hip_beyond_1e4=len(out), fp32_trunk_vs_f16_oracle_median=float(np.median(far)))
-    assert e16.max() < 1e-2 and len(out) <= 0.2 * len(errs), out
-    assert np.median(far) > 3.0 * np.median(e16)   # the oracle's roundings are the ones the kernels apply, not fp32's
+                hip_within_2e4=int((e16 < 2e-4).sum()), hip_beyond_1e3=len(out), torch_fp32_same_oracle_max=float(t32.max()),
+                torch_fp32_same_oracle_beyond_1e3=int((t32 >= 1e-3).sum()), fp32_trunk_vs_f16_oracle_median=float(np.median(far)))
+    assert np.median(e16) < 1e-4 and (e16 < 2e-4).sum() >= 0.6 * len(errs), (np.median(e16), (e16 < 2e-4).sum())
+    assert len(out) <= (t32 >= 1e-3).sum() + 3 and e16.max() <= max(1.25 * t32.max(), 5e-3), (out, e16.max(), t32.max())
+    assert np.median(far) > 10.0 * np.median(e16)   # the oracle's roundings are the ones the kernels apply, not fp32's
     for (n, ba), (_, bc) in zip(model.named_buffers(), ref64.named_buffers()):
         if "running" in n:
             close(ba.cpu(), bc.cpu(), 1e-4)

@@ -163,9 +163,11 @@ def test_deferred_rows_need_a_feature_layout():
 
 def test_reference_amp_branch_runs_unchanged(tmp_path):
     """src/train.py:246-296, the `--use_amp` branch (scaler is not None): forward and loss under torch.cuda.amp.autocast,
-    scaler.scale(loss).backward(), scaler.step, scaler.update -- restated on this package.  The hand-written conv trunk
-    keeps computing in fp32 (a superset of the reference's fp16 autocast convolutions); the FiLM MLP and the attention head
-    run under autocast as torch modules; the InfoNCE kernels take the half-precision embeddings."""
+    scaler.scale(loss).backward(), scaler.step, scaler.update -- restated on this package.  Inside autocast(float16) the
+    hand-written conv trunk switches to its float16-operand kernels by itself (`train_precision = "auto"`: forward, input
+    gradient and weight gradients on v_mfma_f32_16x16x32_f16 with fp32 accumulation, see include/mst.h); the FiLM MLP and the
+    attention head run under autocast as torch modules; the InfoNCE kernels take the half-precision embeddings.  Clips of
+    0.25 s (44 frames) and a batch of 10: ragged 8-clip groups and single-tile planes in every kernel."""
     from mst_amd.data import FMABaselineDataset, baseline_collate_fn
     from mst_amd.loss import InfoNCELoss
     from mst_amd.model import MixingStyleEncoder
@@ -199,3 +201,5 @@ def test_reference_amp_branch_runs_unchanged(tmp_path):
         assert np.isfinite(loss.detach().item()) and embeddings.shape == (10, 768)
     moved = [k for k, v in model.named_parameters() if not torch.equal(v.detach(), before[k])]
     assert len(moved) > 0.9 * len(before) and len(model._warned) == 0
+    assert model._hip_train.train_f16   # the f16 kernels did run
+    assert all(torch.isfinite(v).all() for v in model.parameters())
