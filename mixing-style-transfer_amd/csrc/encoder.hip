@@ -1136,6 +1136,9 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // training forward, last tile row of a plane whose height is 8 k + 1 or 8 k + 2 (rows 8, 9 of 10): only M-tiles 0, 1 hold rows
+    const bool low_rows = MODE == 1 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
+                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;
 #pragma unroll
     for (int st = 0; st < kF16Steps; ++st) {
       h16x8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -1153,6 +1156,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
       for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
+          if (MODE == 1 && t >= 2 && low_rows) continue;   // M-tiles 2, 3 = conv rows 8 tr + 2.. that do not exist (wave-uniform)
           if (TERMS == 3) {
             acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
             acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
@@ -1505,7 +1509,8 @@ __global__ void bn_fold_kernel(const FoldParams p) {   // grid (nsub, B), block 
 }
 
 struct ApplyParams {
-  float* yraw;             // layer 2: the slots of rows past raw_rows are zeroed on the way (the strip kernel does not write them)
+  float* yraw;             // layer 2: the slots of rows past raw_rows / columns past raw_cols are zeroed on the way (the strip kernel
+                           // writes valid positions only; the backward pass reads every slot and 0 * garbage must stay 0)
   int raw_rows;
   const float2* aff;
   float* out;
@@ -1517,6 +1522,7 @@ struct ApplyParams {
   // [clip][band][row][col][32], times the (clip, band) range scale -- the operand layout of conv2_f16x3_kernel
   _Float16* out_h16;
   const float* f16_scale;   // [B][nsub][2] = (s, 1/s)
+  int raw_cols;             // layer 2: valid columns of the convolution output plane
 };
 
 template <int LAYER, int SUB>
@@ -1540,8 +1546,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
   for (int t = 0; t < C::MT; ++t) {
     f32x4 q = src[t];
     if constexpr (LAYER == 2) {
+      const int col0 = 8 * tc + 4 * (g & 1);
       if (8 * tr + 4 * (g >> 1) + t >= p.raw_rows) {   // no such output row: keep the slot finite for the backward pass
         q = f32x4{0.f, 0.f, 0.f, 0.f};
+        src[t] = q;
+      } else if (col0 + 3 >= p.raw_cols) {             // columns past the plane (the strip kernel never writes them)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col0 + r >= p.raw_cols) q[r] = 0.f;
         src[t] = q;
       }
     }
@@ -1680,7 +1692,9 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
     unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
-      const float zh = (v[e] - ms.x) * ms.y;
+      int row, col;
+      unit_geometry<LAYER, SUB>(tr, tc, g, e, row, col);
+      const float zh = (row < p.rows && col < p.cols) ? (v[e] - ms.x) * ms.y : 0.f;   // padding slots: df is 0 there, keep 0 * x finite
       dgam = fmaf(df[e], fmaf(gb, zh, bb), dgam);
       dbet += df[e];
       const double dz = (double)gf * (double)df[e];
@@ -2668,7 +2682,7 @@ namespace {
 struct TrainLayout {
   WsLayout base;
   size_t y1, y2, stats1, stats2, bn1, bn2, dfilm_acc, dw_acc, total;
-  size_t t_pool1_h16, t_f16scale, t_xmax, t_bscale;   // f16 training only (0 bytes otherwise)
+  size_t t_pool1_h16, t_f16scale, t_xmax, t_bscale, t_dyg1, t_dyg2;   // f16 training only (0 bytes otherwise)
   int tr1, tc1, tr2, tc2;
 };
 TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
@@ -2697,6 +2711,9 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   T.t_f16scale = take(f * (size_t)B * ns * 2 * 4);
   T.t_xmax = take(f * (size_t)B * 4);
   T.t_bscale = take(f * 16);                                                // (s, 1/s) of the backward pass + the max |d pool_in| bits
+  const size_t cgs = (size_t)((B + 7) / 8);                                 // d(conv output) as f16 in the weight gradients' operand layout
+  T.t_dyg1 = take(f * (size_t)ns * cgs * T.tr1 * T.tc1 * 2 * 20 * 64 * 16);
+  T.t_dyg2 = take(f * (size_t)ns * cgs * T.tr2 * T.tc2 * 4 * 16 * 64 * 16);
   T.total = o;
   return T;
 }
@@ -2796,7 +2813,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
                   ns, 32, 0, 32};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
-                   B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr};
+                   B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr, frames};
     if (e->train_f16) {   // range scale of conv2's f16 operand: one power of two per band from a bound on the pooled values
       unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);
       float* fsc = reinterpret_cast<float*>(ws + T.t_f16scale);
@@ -2878,7 +2895,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn2);
     FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
-    ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64};
+    ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64,
+                   nullptr, nullptr, L.W1};
     hipLaunchKernelGGL((apply_kernel<2, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -2969,7 +2987,19 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   p.chunks = std::max(1, std::min(16, wus / 64));
   const long long units = (long long)B * ns * wus * 64;
   const dim3 gr(p.chunks, B * ns), gd((unsigned)((units + 255) / 256));
-  if (layer == 1 && e->sub == 2) {
+  if (e->train_f16) {   // pass A unchanged; pass B writes f16 d(conv output) in the weight gradient's operand layout
+    MST_REQUIRE(layer == 2 || dy == nullptr, "mst_encoder_train_backward_apply: f16 training keeps layer 1's dy in the workspace (pass dy = NULL)");
+    const int CG = (B + 7) / 8;
+    const long long gunits = (long long)ns * CG * wus * 64;
+    const dim3 gg((unsigned)((gunits + 255) / 256));
+    if (layer == 1) {
+      hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2>), gg, dim3(256), 0, st, p, gunits, reinterpret_cast<h16x8*>(ws + T.t_dyg1), CG);
+    } else {
+      hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
+      hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2>), gg, dim3(256), 0, st, p, gunits, reinterpret_cast<h16x8*>(ws + T.t_dyg2), CG);
+    }
+  } else if (layer == 1 && e->sub == 2) {
     hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
     hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 2>), gd, dim3(256), 0, st, p, units);
   } else if (layer == 1) {
@@ -3052,7 +3082,7 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
   const float* unscale = nullptr;
   if (e->train_f16) {   // f16 operands, K = positions x 8 clips (encoder_f16train.inc)
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
-    WgradF16Params fp{logmel, reinterpret_cast<const float*>(ws + T.y1), dwa, nullptr, B, ns, T.tr1, T.tc1,
+    WgradF16Params fp{logmel, reinterpret_cast<const h16x8*>(ws + T.t_dyg1), dwa, nullptr, B, ns, T.tr1, T.tc1,
                       e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
                       (long long)8 * e->cfg.n_mels * frames};
     const long long items = (long long)ns * ((B + 7) / 8) * T.tr1 * T.tc1;
@@ -3094,7 +3124,7 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   const float* unscale = nullptr;
   if (e->train_f16) {
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
-    WgradF16Params fp{pool1, reinterpret_cast<const float*>(ws + T.y2), dwa, reinterpret_cast<const float*>(ws + T.t_f16scale),
+    WgradF16Params fp{pool1, reinterpret_cast<const h16x8*>(ws + T.t_dyg2), dwa, reinterpret_cast<const float*>(ws + T.t_f16scale),
                       B, ns, T.tr2, T.tc2, e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1};
     const long long items = (long long)ns * ((B + 7) / 8) * T.tr2 * T.tc2;
     constexpr size_t lds = (size_t)(8 * 14 * 14 + 4 * 16 * 64) * 16;

@@ -239,6 +239,8 @@ class HipEncoder:
             raise _lib.MstError("forward_train needs frames >= 20")
         if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need or self._ws_train.device != logmel.device:
             self._ws_train = torch.empty(need, dtype=torch.uint8, device=logmel.device)
+        if _POISON_WS:   # debugging aid: every byte 0xFF (fp32 NaN) before each forward -- any read of a slot nobody wrote shows up
+            self._ws_train.fill_(255)
         dev = logmel.device
         emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=dev) if head else None
         W1 = Fr // 5
@@ -351,6 +353,8 @@ class HipEncoder:
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
         if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=logmel.device)
+        if _POISON_WS:
+            self._ws.fill_(255)
         emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=logmel.device)
         t, out = None, {}
         if taps:
@@ -373,6 +377,7 @@ class HipEncoder:
 
 
 _TRAIN_TIMING = bool(os.environ.get("MST_TRAIN_TIMING"))
+_POISON_WS = bool(os.environ.get("MST_POISON_WS"))
 _CONV1_WGRAD_MIOPEN = os.environ.get("MST_CONV1_WGRAD", "") == "miopen"
 # library (MIOpen, via aten.convolution_backward) versions of the three convolution gradients, kept for A/B checks only
 _CONV2_WGRAD_MIOPEN = os.environ.get("MST_CONV2_WGRAD", "") == "miopen"

@@ -306,6 +306,42 @@ def test_train_mode_forward_batch_statistics(T, B):
     assert (emb - e_eval).abs().max().item() > 1e-3 * e_eval.abs().max().item()   # it is NOT the eval forward
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_results_do_not_depend_on_workspace_contents(precision):
+    """Every slot of the activation workspace that a kernel reads must have been written by a kernel of the same step: with
+    the workspace filled with 0xFF bytes (fp32 NaN, int64 -1) before each forward, the eval embeddings and a training
+    step's loss and gradients are bit-identical to those of a run on whatever the allocator handed out.  (Found the hard
+    way: conv2's raw-output slots right of the plane in the 2-row strip were read by the backward reduction as 0 * x.)"""
+    from mst_amd import model as mm
+    cfg = cases.CFG_DEFAULT
+    B, T = 5, 44100 + 256 * 3   # 176 frames: W1 = 35 (partial 8-column tile in conv2), W2 = 8
+    x = torch.stack([cases.synth_clip(c % 4, T) for c in range(B)], 0).cuda()
+    g = torch.Generator().manual_seed(11)
+    feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
+    R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
+    results = []
+    try:
+        for poison in (False, True):
+            mm._POISON_WS = poison
+            model, _ = build_model(cfg)
+            with torch.no_grad():
+                lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
+                e_eval = model.forward_from_logmel(lm, feats).clone()
+            model.train()
+            model.train_backend, model.train_precision = "hip-strict", precision
+            torch.manual_seed(3)   # Dropout masks
+            loss = (model.forward_from_logmel(lm, feats) * R).sum()
+            loss.backward()
+            results.append((e_eval, loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}))
+    finally:
+        mm._POISON_WS = False
+    (ea, la, ga), (eb, lb, gb) = results
+    assert torch.isfinite(eb).all() and torch.equal(ea, eb)
+    assert torch.isfinite(lb) and torch.equal(la, lb)
+    bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    assert not bad, bad[:5]
+
+
 def _stacked_trunk_params(model):
     cn = model.audio_encoder.subnet_cnns
     st = lambda f: torch.stack([f(c) for c in cn]).detach()  # noqa: E731
