@@ -48,9 +48,10 @@ def parse():
                     help="extra measurement, not the contract line: a full TRAINING step (stage A, encoder forward + backward "
                          "with train-mode BatchNorm and Dropout, InfoNCE forward + backward, AdamW) instead of the forward path")
     ap.add_argument("--train-backend", choices=["hip", "torch"], default="hip")
-    ap.add_argument("--train-precision", choices=["fp32", "f16", "amp"], default="fp32",
+    ap.add_argument("--train-precision", choices=["fp32", "f16", "f16x3", "amp"], default="fp32",
                     help="--train only.  fp32: exact fp32 MFMA trunk.  f16: the hand-written trunk with float16 operands / fp32 "
-                         "accumulation (BASELINE configs[4]'s fp16), everything else fp32.  amp: the reference's --use_amp step "
+                         "accumulation (BASELINE configs[4]'s fp16), everything else fp32.  f16x3: the same kernels with 3-term split-precision "
+                         "operands (fp32-equivalent results).  amp: the reference's --use_amp step "
                          "(src/train.py:246-262): forward and loss under torch.autocast(float16), GradScaler; the trunk "
                          "switches to its f16 kernels by itself, the torch backend runs MIOpen's half convolutions")
     ap.add_argument("--ingest", choices=["resident", "f32", "pcm16"], default="resident",
@@ -272,7 +273,7 @@ def main():
     if a.train:   # training step: same data, same metric unit; reported with its own workload string
         model.train()
         model.train_backend = a.train_backend
-        model.train_precision = {"fp32": "fp32", "f16": "f16", "amp": "auto"}[a.train_precision]
+        model.train_precision = {"fp32": "fp32", "f16": "f16", "f16x3": "f16x3", "amp": "auto"}[a.train_precision]
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
         crit_t = InfoNCELoss(0.1, gather=world > 1)
         amp = a.train_precision == "amp"
@@ -321,6 +322,7 @@ def main():
                 "warmup": max(a.warmup, 5),
                 "ms_per_step": round(t.item() / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": {"fp32": "f32", "f16": "f16 operands / f32 accumulate (conv trunk)",
+                                               "f16x3": "f32-equivalent (conv trunk on 3-term split-precision f16 MFMA, f32 accumulate)",
                                                "amp": "autocast f16 + GradScaler"}[a.train_precision], "data": "synthetic",
                 "config": {"workload": f"NOT THE CONTRACT LINE -- full TRAINING step ({a.train_backend} encoder backend, "
                                        f"precision {a.train_precision}): HIP stage A, "

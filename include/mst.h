@@ -179,10 +179,14 @@ int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int f
  * output channel; pool1 per band from a bound on its values; the gradients by one factor per backward pass from
  * max |d pool_in| -- the internal equivalent of the reference's loss scale) and the factor is divided out in fp32, so neither
  * f16's ceiling nor its subnormals are reached; no host synchronisation.  Needs 20-mel sub-bands.
- * In mode 1 the `dy` of mst_encoder_train_backward_apply(layer 2) and the `dy2` of mst_encoder_train_conv2_dgrad are a
- * float16 buffer [n_sub][B][H1][W1][64] (channel-minor; pass it through), and d pool_in must be contiguous.
+ * 2: the same kernels with THREE-TERM SPLIT PRECISION -- every operand is a pair hi + lo of float16 (22 significant bits),
+ * a product is lo*hi + hi*lo + hi*hi in three MFMAs, fp32 accumulation: results equivalent to the fp32 kernels (tested at
+ * their bar) at a third of the f16 matrix rate, i.e. ~5x the fp32 rate.
+ * In modes 1 and 2 the `dy` of mst_encoder_train_backward_apply(layer 2) and the `dy2` of mst_encoder_train_conv2_dgrad are
+ * a float16 buffer [n_sub][B][H1][W1][64] (channel-minor; mode 2: [2][n_sub][B][H1][W1][64], low parts second; pass it
+ * through), layer 1's dy must be NULL, and d pool_in must be contiguous.
  * Call before mst_encoder_train_workspace_bytes and mst_encoder_update_trunk_params.                              */
-int mst_encoder_set_train_precision(mst_encoder* enc, int f16_operands);
+int mst_encoder_set_train_precision(mst_encoder* enc, int mode);
 
 /* Refresh the convolution / BatchNorm parameters of the TRAINING kernels from device tensors (concatenated over the
  * sub-bands, reference state_dict shapes) -- once per optimizer step; re-swizzles the MFMA weight fragments on the

@@ -1136,34 +1136,40 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // training forward, last tile row of a plane whose height is 8 k + 1 or 8 k + 2 (rows 8, 9 of 10): only M-tiles 0, 1 hold rows
-    const bool low_rows = MODE == 1 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
-                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;
+    // training forward, last tile row of a plane whose height is 8 k + 1 or 8 k + 2 (rows 8, 9 of 10): only M-tiles 0, 1 hold
+    // rows that exist.  Two straight-line instantiations of the k-step loop, chosen per tile (wave-uniform): a branch around
+    // single MFMAs inside one loop breaks the software pipeline.
+    auto ksteps = [&](auto mtx_c) __attribute__((always_inline)) {
+      constexpr int MTX = decltype(mtx_c)::value;
 #pragma unroll
-    for (int st = 0; st < kF16Steps; ++st) {
-      h16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
-        if (TERMS == 3) bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
-      }
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        ah[t] = phi[abase[t] + toff[st]];
-        if (TERMS == 3) al[t] = plo[abase[t] + toff[st]];
-      }
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
+      for (int st = 0; st < kF16Steps; ++st) {
+        h16x8 ah[MTX], al[MTX], bh[NT], bl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          if (MODE == 1 && t >= 2 && low_rows) continue;   // M-tiles 2, 3 = conv rows 8 tr + 2.. that do not exist (wave-uniform)
-          if (TERMS == 3) {
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
-          }
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
+          bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
+          if (TERMS == 3) bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
         }
-    }
+#pragma unroll
+        for (int t = 0; t < MTX; ++t) {
+          ah[t] = phi[abase[t] + toff[st]];
+          if (TERMS == 3) al[t] = plo[abase[t] + toff[st]];
+        }
+#pragma unroll
+        for (int t = 0; t < MTX; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (TERMS == 3) {
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
+            }
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
+          }
+      }
+    };
+    const bool low_rows = MODE == 1 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
+                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;
+    if (MODE == 1 && low_rows) ksteps(std::integral_constant<int, 2>{});
+    else ksteps(std::integral_constant<int, MT>{});
     if (MODE == 1 && chunk == NCH - 1 && cur.valid) {
       const int j = lane & 15, g = lane >> 4;
       if (cur.band != st_band) {
@@ -1420,6 +1426,11 @@ struct mst_encoder {
 
 namespace {
 
+// training precision modes (mst_encoder_set_train_precision): 0 fp32 MFMA; 1 f16 operands; 2 three-term split-precision f16
+// (fp32-equivalent) -- both on the f16 matrix cores, forward and backward (encoder_f16train.inc)
+inline bool train_fwd16(const mst_encoder* e) { return e->train_f16 != 0; }
+inline bool train_bwd16(const mst_encoder* e) { return e->train_f16 != 0; }
+
 struct WsLayout {
   size_t film, aff1, aff2, pool1, pool1_h16, pool1_l16, f16scale, xmax, pool_in, scores, pooled, total;
   int W1, W2;
@@ -1523,6 +1534,7 @@ struct ApplyParams {
   _Float16* out_h16;
   const float* f16_scale;   // [B][nsub][2] = (s, 1/s)
   int raw_cols;             // layer 2: valid columns of the convolution output plane
+  _Float16* out_l16;        // split-precision training forward: the low part (v * s - hi) next to out_h16
 };
 
 template <int LAYER, int SUB>
@@ -1571,9 +1583,13 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
         const size_t o = ((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + tr) * p.out_cols + pc;
         const float v = p.mask ? (p.mask[o] ? m * p.mask_scale : 0.f) : m;
         p.out[o] = v;
-        if (p.out_h16)
-          p.out_h16[((((size_t)clip * p.nsub + band) * p.out_rows + tr) * p.out_cols + pc) * 32 + ch] =
-              (_Float16)(v * p.f16_scale[((size_t)clip * p.nsub + band) * 2]);
+        if (p.out_h16) {
+          const size_t o16 = ((((size_t)clip * p.nsub + band) * p.out_rows + tr) * p.out_cols + pc) * 32 + ch;
+          const float vs = v * p.f16_scale[((size_t)clip * p.nsub + band) * 2];
+          const _Float16 h = (_Float16)vs;
+          p.out_h16[o16] = h;
+          if (p.out_l16) p.out_l16[o16] = (_Float16)(vs - (float)h);
+        }
       }
     }
   } else {
@@ -2488,11 +2504,11 @@ int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
 
 int mst_encoder_set_train_precision(mst_encoder* e, int f16_operands) {
   MST_REQUIRE(e, "mst_encoder_set_train_precision: NULL encoder");
-  MST_REQUIRE(f16_operands == 0 || (f16_operands == 1 && e->sub == 2),
-              "mst_encoder_set_train_precision: the f16-operand training kernels need the default 20-mel sub-bands (pool height 2)");
+  MST_REQUIRE(f16_operands == 0 || ((f16_operands == 1 || f16_operands == 2) && e->sub == 2),
+              "mst_encoder_set_train_precision: modes 1 (f16 operands) and 2 (split-precision forward) need the default 20-mel sub-bands (pool height 2)");
   if (f16_operands && !e->w2dfrag16) {
     const int ns = e->cfg.n_subbands;
-    bool ok = hipMalloc(&e->w2dfrag16, (size_t)ns * 8 * kF16Steps * 2 * 64 * 8 * sizeof(_Float16)) == hipSuccess;
+    bool ok = hipMalloc(&e->w2dfrag16, (size_t)ns * 8 * kF16Steps * 2 * 2 * 64 * 8 * sizeof(_Float16)) == hipSuccess;   // room for hi + lo
     ok = ok && hipMalloc(&e->f16_wsc1, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_wsc2, (size_t)ns * 64 * 4) == hipSuccess;
     ok = ok && hipMalloc(&e->f16_wsc2d, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_winv2d, (size_t)ns * 32 * 4) == hipSuccess;
     if (!ok) return mst::fail(MST_ENOMEM, "mst_encoder_set_train_precision: out of device memory");
@@ -2682,7 +2698,7 @@ namespace {
 struct TrainLayout {
   WsLayout base;
   size_t y1, y2, stats1, stats2, bn1, bn2, dfilm_acc, dw_acc, total;
-  size_t t_pool1_h16, t_f16scale, t_xmax, t_bscale, t_dyg1, t_dyg2;   // f16 training only (0 bytes otherwise)
+  size_t t_pool1_h16, t_pool1_l16, t_f16scale, t_xmax, t_bscale, t_dyg1, t_dyg2;   // f16 training modes only (0 bytes otherwise)
   int tr1, tc1, tr2, tc2;
 };
 TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
@@ -2706,14 +2722,16 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   T.bn2 = take((size_t)ns * 64 * 8);
   T.dfilm_acc = take((size_t)B * ns * 192 * sizeof(mst::DetAcc));
   T.dw_acc = take((size_t)ns * 64 * 1568 * sizeof(mst::DetAcc));   // weight-gradient accumulators (conv2's size; conv1 reuses it)
-  const size_t f = e->train_f16 ? 1 : 0;
+  const size_t f = train_fwd16(e) ? 1 : 0, fb = train_bwd16(e) ? 1 : 0;
   T.t_pool1_h16 = take(f * (size_t)B * ns * 32 * e->H1 * T.base.W1 * 2);   // pool1 as f16, channel-minor (conv2's operand)
+  T.t_pool1_l16 = take((e->train_f16 == 2 ? 1 : 0) * (size_t)B * ns * 32 * e->H1 * T.base.W1 * 2);   // its low part (split precision)
   T.t_f16scale = take(f * (size_t)B * ns * 2 * 4);
   T.t_xmax = take(f * (size_t)B * 4);
-  T.t_bscale = take(f * 16);                                                // (s, 1/s) of the backward pass + the max |d pool_in| bits
+  T.t_bscale = take(fb * 16);                                               // (s, 1/s) of the backward pass + the max |d pool_in| bits
   const size_t cgs = (size_t)((B + 7) / 8);                                 // d(conv output) as f16 in the weight gradients' operand layout
-  T.t_dyg1 = take(f * (size_t)ns * cgs * T.tr1 * T.tc1 * 2 * 20 * 64 * 16);
-  T.t_dyg2 = take(f * (size_t)ns * cgs * T.tr2 * T.tc2 * 4 * 16 * 64 * 16);
+  const size_t hl = e->train_f16 == 2 ? 2 : 1;                              // split precision: hi and lo
+  T.t_dyg1 = take(fb * hl * (size_t)ns * cgs * T.tr1 * T.tc1 * 2 * 20 * 64 * 16);
+  T.t_dyg2 = take(fb * hl * (size_t)ns * cgs * T.tr2 * T.tc2 * 4 * 16 * 64 * 16);
   T.total = o;
   return T;
 }
@@ -2774,18 +2792,23 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.yraw = y1, cp.stats = stats1, cp.bias = e->c1b, cp.raw_rows = e->cfg.split_size, cp.raw_cols = frames;
     cp.acc_tr = T.tr1, cp.acc_tc = T.tc1;
     const int g = std::min(grid, ns * cp.sets_per_band);
-    if (e->train_f16) {   // f16 operands, fp32 accumulate (encoder_f16train.inc)
+    if (train_fwd16(e)) {   // f16 operands (mode 1) or 3-term split precision (mode 2), fp32 accumulate (encoder_f16train.inc)
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (f16 train) attribute failed: %s", hipGetErrorString(err));
       }
       cp.f16_winv = e->f16_winv1;
-      hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp,
-                         reinterpret_cast<const h16x8*>(e->w1frag16), static_cast<_Float16*>(nullptr), static_cast<_Float16*>(nullptr));
+      const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
+      _Float16* none = nullptr;
+      if (e->train_f16 == 2) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
+      else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
     } else if (e->sub == 2) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
@@ -2814,7 +2837,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
                    B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr, frames};
-    if (e->train_f16) {   // range scale of conv2's f16 operand: one power of two per band from a bound on the pooled values
+    if (train_fwd16(e)) {   // range scale of conv2's f16 operand: one power of two per band from a bound on the pooled values
       unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);
       float* fsc = reinterpret_cast<float*>(ws + T.t_f16scale);
       MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
@@ -2823,6 +2846,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       hipLaunchKernelGGL(f16_scale_band_kernel, dim3(ns), dim3(64), 0, st, aff1, e->w1norm, xmax, e->c1b,
                          (taps && taps->drop1_mask) ? taps->drop1_scale : 1.f, fsc, B, ns);
       ap.out_h16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_h16), ap.f16_scale = fsc;
+      if (e->train_f16 == 2) ap.out_l16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_l16);
     }
     if (e->sub == 2) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     else hipLaunchKernelGGL((apply_kernel<1, 1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
@@ -2844,7 +2868,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     cp.yraw = y2, cp.stats = stats2, cp.bias = e->c2b, cp.raw_rows = e->H1, cp.raw_cols = L.W1;
     cp.acc_tr = T.tr2, cp.acc_tc = T.tc2;
-    if (e->train_f16) {   // all tile rows on the f16 kernel (no strip: its padding costs less than a second launch)
+    if (train_fwd16(e)) {   // all tile rows on the f16 kernel (no strip: its padding costs less than a second launch)
       cp.tiles_r = T.tr2;
       cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
       const int g = std::min(grid, ns * cp.sets_per_band);
@@ -2853,13 +2877,19 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<1, 1>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<3, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 (f16 train) attribute failed: %s", hipGetErrorString(err));
       }
       cp.f16_scale = reinterpret_cast<const float*>(ws + T.t_f16scale);
       cp.f16_winv = e->f16_winv2;
       const h16x8* ih = reinterpret_cast<const h16x8*>(ws + T.t_pool1_h16);
-      hipLaunchKernelGGL((conv2_f16x3_kernel<1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, ih,
-                         reinterpret_cast<const h16x8*>(e->w2frag16));
+      const h16x8* wf2 = reinterpret_cast<const h16x8*>(e->w2frag16);
+      if (e->train_f16 == 2)
+        hipLaunchKernelGGL((conv2_f16x3_kernel<3, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih,
+                           reinterpret_cast<const h16x8*>(ws + T.t_pool1_l16), wf2);
+      else hipLaunchKernelGGL((conv2_f16x3_kernel<1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, ih, wf2);
       MST_HIP_CHECK(hipGetLastError());
     } else {
       const int g = std::min(grid, ns * cp.sets_per_band);
@@ -2874,7 +2904,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       hipLaunchKernelGGL((conv_kernel<2, 2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
       MST_HIP_CHECK(hipGetLastError());
     }
-    if (strip && !e->train_f16) {
+    if (strip && !train_fwd16(e)) {
       ConvParams sp = cp;
       sp.row_off = 8 * (T.tr2 - 1);
       sp.tiles_r = (rows_last + 1) / 2, sp.tiles_c = (L.W1 + 39) / 40;
@@ -2952,7 +2982,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   // the start of the trunk's backward); d pool1 carries it to layer 1; every result that leaves the trunk is divided by s.
   // In this mode `dy` of layer 2 is the f16 channel-minor operand of the f16 dgrad kernel, [n_sub][B][H1][W1][64] halves.
   const float* unscale = nullptr;
-  if (e->train_f16) {
+  if (train_bwd16(e)) {
     float* bs = reinterpret_cast<float*>(ws + T.t_bscale);
     unscale = bs;
     if (layer == 2) {
@@ -2987,17 +3017,22 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   p.chunks = std::max(1, std::min(16, wus / 64));
   const long long units = (long long)B * ns * wus * 64;
   const dim3 gr(p.chunks, B * ns), gd((unsigned)((units + 255) / 256));
-  if (e->train_f16) {   // pass A unchanged; pass B writes f16 d(conv output) in the weight gradient's operand layout
+  if (train_bwd16(e)) {   // pass A unchanged; pass B writes f16 d(conv output) in the weight gradient's operand layout
     MST_REQUIRE(layer == 2 || dy == nullptr, "mst_encoder_train_backward_apply: f16 training keeps layer 1's dy in the workspace (pass dy = NULL)");
     const int CG = (B + 7) / 8;
     const long long gunits = (long long)ns * CG * wus * 64;
     const dim3 gg((unsigned)((gunits + 255) / 256));
+    const bool x3 = e->train_f16 == 2;
     if (layer == 1) {
+      h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg1);
       hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
-      hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2>), gg, dim3(256), 0, st, p, gunits, reinterpret_cast<h16x8*>(ws + T.t_dyg1), CG);
+      if (x3) hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2, 3>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
+      else hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2, 1>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
     } else {
+      h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg2);
       hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
-      hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2>), gg, dim3(256), 0, st, p, gunits, reinterpret_cast<h16x8*>(ws + T.t_dyg2), CG);
+      if (x3) hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2, 3>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
+      else hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2, 1>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
     }
   } else if (layer == 1 && e->sub == 2) {
     hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
@@ -3036,7 +3071,7 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
                        ConvGeom<3, 2>::WBP);
     MST_HIP_CHECK(hipGetLastError());
   }
-  if (e->train_f16) {   // f16 fragments of the new weights: per-channel power-of-two pre-scale, then hi/lo (forward) / hi (dgrad)
+  if (train_fwd16(e)) {   // f16 fragments of the new weights: per-channel power-of-two pre-scale, then hi/lo (forward) / hi (dgrad)
     hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 32), dim3(64), 0, st, conv1_w, 32, (long long)32 * 392, 392, 1, 0, 392,
                        e->f16_wsc1, e->f16_winv1, e->w1norm);
     hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 64), dim3(64), 0, st, conv2_w, 64, (long long)64 * 1568, 1568, 1, 0, 1568,
@@ -3050,7 +3085,7 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
     hipLaunchKernelGGL(f16_fragments_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, conv2_w, e->f16_wsc2,
                        reinterpret_cast<_Float16*>(e->w2frag16), ns, 64, 32, 2, 0);
     hipLaunchKernelGGL(f16_fragments_kernel, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, conv2_w, e->f16_wsc2d,
-                       reinterpret_cast<_Float16*>(e->w2dfrag16), ns, 32, 64, 1, 1);
+                       reinterpret_cast<_Float16*>(e->w2dfrag16), ns, 32, 64, e->train_f16 == 2 ? 2 : 1, 1);
     MST_HIP_CHECK(hipGetLastError());
   }
   const struct { float* dst; const float* src; int n; } cp[] = {
@@ -3080,20 +3115,25 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv1_wgrad: too many tiles");
   const int g8 = (int)std::min<long long>(e->num_cus, total);
   const float* unscale = nullptr;
-  if (e->train_f16) {   // f16 operands, K = positions x 8 clips (encoder_f16train.inc)
+  if (train_bwd16(e)) {   // f16 operands, K = positions x 8 clips (encoder_f16train.inc)
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
     WgradF16Params fp{logmel, reinterpret_cast<const h16x8*>(ws + T.t_dyg1), dwa, nullptr, B, ns, T.tr1, T.tc1,
                       e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
                       (long long)8 * e->cfg.n_mels * frames};
     const long long items = (long long)ns * ((B + 7) / 8) * T.tr1 * T.tc1;
-    constexpr size_t lds = (size_t)(8 * 8 * 46 + 2 * 20 * 64) * 16;
+    constexpr size_t lds1 = (size_t)(8 * 8 * 46 + 2 * 20 * 64) * 16, lds3 = (size_t)(2 * 8 * 8 * 46 + 2 * 10 * 2 * 64) * 16;
     static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
     if (mst::first_use_on_device(attr_set)) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 wgrad (f16) attribute failed: %s", hipGetErrorString(err));
     }
-    hipLaunchKernelGGL((wgrad_f16_kernel<1>), dim3((int)std::min<long long>(e->num_cus, items)), dim3(kConvThreads), lds, st, fp);
+    const dim3 gw((int)std::min<long long>(e->num_cus, items));
+    if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<1, 3>), gw, dim3(kConvThreads), lds3, st, fp);
+    else hipLaunchKernelGGL((wgrad_f16_kernel<1, 1>), gw, dim3(kConvThreads), lds1, st, fp);
   } else if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
   hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw, unscale);
@@ -3122,19 +3162,24 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
   const int g = (int)std::min<long long>(e->num_cus & ~3, 4 * total);   // groups of 4 workgroups (one per input-channel chunk)
   const float* unscale = nullptr;
-  if (e->train_f16) {
+  if (train_bwd16(e)) {
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
     WgradF16Params fp{pool1, reinterpret_cast<const h16x8*>(ws + T.t_dyg2), dwa, reinterpret_cast<const float*>(ws + T.t_f16scale),
                       B, ns, T.tr2, T.tc2, e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1};
     const long long items = (long long)ns * ((B + 7) / 8) * T.tr2 * T.tc2;
-    constexpr size_t lds = (size_t)(8 * 14 * 14 + 4 * 16 * 64) * 16;
+    constexpr size_t lds1 = (size_t)(8 * 14 * 14 + 4 * 16 * 64) * 16, lds3 = (size_t)(2 * 8 * 14 * 14 + 4 * 8 * 2 * 64) * 16;
     static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
     if (mst::first_use_on_device(attr_set)) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2, 1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 wgrad (f16) attribute failed: %s", hipGetErrorString(err));
     }
-    hipLaunchKernelGGL((wgrad_f16_kernel<2>), dim3((int)std::min<long long>(e->num_cus & ~3, 4 * items)), dim3(kConvThreads), lds, st, fp);
+    const dim3 gw((int)std::min<long long>(e->num_cus & ~3, 4 * items));
+    if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<2, 3>), gw, dim3(kConvThreads), lds3, st, fp);
+    else hipLaunchKernelGGL((wgrad_f16_kernel<2, 1>), gw, dim3(kConvThreads), lds1, st, fp);
   } else {
     hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);
   }
@@ -3161,17 +3206,23 @@ int mst_encoder_train_conv2_dgrad(const mst_encoder* e, const float* dy2, int B,
   cp.raw_rows = H1, cp.raw_cols = W1, cp.mask = drop1_mask, cp.mask_scale = drop1_scale;
   MST_REQUIRE((long long)cp.in_bandoff * ns < (1LL << 31), "mst_encoder_train_conv2_dgrad: batch too large for 32-bit band offsets");
   const int g = std::min(e->num_cus, ns * cp.sets_per_band);
-  if (e->train_f16) {   // dy2 holds f16, channel-minor [n_sub][B][H1][W1][64] (mst_encoder_train_backward_apply in this mode)
-    constexpr size_t lds = (size_t)(kF16Steps * 2 * 64 + kConvWaves * 8 * 46) * 16;
+  if (train_bwd16(e)) {   // dy2 holds f16, channel-minor [n_sub][B][H1][W1][64] (mst_encoder_train_backward_apply in this mode)
+    constexpr size_t lds1 = (size_t)(kF16Steps * 2 * 64 + kConvWaves * 8 * 46) * 16, lds3 = 2 * lds1;
     static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
     if (mst::first_use_on_device(attr_set)) {
-      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_f16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_f16_kernel<1>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_dgrad_f16_kernel<3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 dgrad (f16) attribute failed: %s", hipGetErrorString(err));
     }
     cp.f16_winv = e->f16_winv2d;
-    hipLaunchKernelGGL(conv2_dgrad_f16_kernel, dim3(g), dim3(kConvThreads), lds, st, cp, reinterpret_cast<const h16x8*>(dy2),
-                       reinterpret_cast<const h16x8*>(e->w2dfrag16));
+    const h16x8* dh = reinterpret_cast<const h16x8*>(dy2);
+    const h16x8* wf = reinterpret_cast<const h16x8*>(e->w2dfrag16);
+    if (e->train_f16 == 2)   // split precision: the low parts follow the high parts, [2][n_sub][B][H1][W1][64]
+      hipLaunchKernelGGL(conv2_dgrad_f16_kernel<3>, dim3(g), dim3(kConvThreads), lds3, st, cp, dh, dh + (size_t)ns * B * H1 * W1 * 8, wf);
+    else hipLaunchKernelGGL(conv2_dgrad_f16_kernel<1>, dim3(g), dim3(kConvThreads), lds1, st, cp, dh, dh, wf);
     MST_HIP_CHECK(hipGetLastError());
     return MST_OK;
   }

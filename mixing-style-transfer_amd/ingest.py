@@ -143,11 +143,13 @@ class DeviceStager:
         stager = DeviceStager((N, 8, C), torch.int16, device)
         fut = stager.submit(batch0)                  # memcpy into pinned slot, enqueue H2D on the copy stream
         for nxt in batches:
-            x = fut.get()                            # compute stream waits on the copy's event (no host sync)
+            cur, x = fut, fut.get()                  # compute stream waits on the copy's event (no host sync)
             fut = stager.submit(nxt)                 # next copy overlaps the kernels launched below
             ... kernels on x ...
-    A slot is reused every `depth` submits; `get()` of the batch that used it before must have been consumed on the
-    compute stream by then -- the stager records that with an event and makes the copy stream wait on it."""
+            stager.release(cur)                      # REQUIRED: marks x's slot as consumed up to this point of the stream
+    A slot is reused every `depth` submits.  `release()` records an event on the compute stream after the last kernel that
+    reads the slot; the H2D copy that reuses the slot waits on it.  Without the `release()` call the next copy into the slot
+    may overwrite a buffer that kernels are still reading."""
 
     class _Future:
         def __init__(self, dev_buf, ready, slot):

@@ -213,7 +213,7 @@ class HipEncoder:
         self.mode = modes[conv1_precision]
         _lib.check(_lib.lib().mst_encoder_set_precision(h, self.mode), "mst_encoder_set_precision")
         self._ws = None
-        self.train_f16 = False   # operand precision of the training kernels (set_train_precision)
+        self.train_mode, self.train_f16 = 0, False   # precision of the training kernels (set_train_precision)
         self.embed_dim = ae.attention_pooling.output_dim
         self.n_sub, self.split, self.freq_dim, self.overlap = ae.n_subbands, ae.split_size, ae.freq_dim, ae.overlap
         self.sub = max(1, ae.split_size // 10)   # pool height of the first max-pool
@@ -262,13 +262,19 @@ class HipEncoder:
                        "mst_encoder_forward_train")
         return emb, out
 
-    def set_train_precision(self, f16: bool):
-        """Operand precision of the training kernels (`mst_encoder_set_train_precision`): False = exact fp32 MFMA, True =
-        float16 operands with fp32 accumulation (the reference's --use_amp arithmetic).  Takes effect with the next
-        `update_trunk_params` + `forward_train` pair."""
-        if bool(f16) != getattr(self, "train_f16", False):
-            _lib.check(_lib.lib().mst_encoder_set_train_precision(self._h, 1 if f16 else 0), "mst_encoder_set_train_precision")
-            self.train_f16 = bool(f16)
+    TRAIN_MODES = {"fp32": 0, "f16": 1, "f16x3": 2}
+
+    def set_train_precision(self, mode):
+        """Precision of the training kernels (`mst_encoder_set_train_precision`): "fp32" / False = exact fp32 MFMA;
+        "f16" / True = float16 operands with fp32 accumulation in the forward and backward convolutions (the reference's
+        --use_amp arithmetic); "f16x3" = the same kernels with 3-term split-precision operands (hi + lo float16 pairs,
+        fp32-equivalent results at ~5x the fp32 matrix rate).  Takes effect with the next `update_trunk_params` +
+        `forward_train` pair."""
+        m = self.TRAIN_MODES[mode] if isinstance(mode, str) else (1 if mode else 0)
+        if m != self.train_mode:
+            _lib.check(_lib.lib().mst_encoder_set_train_precision(self._h, m), "mst_encoder_set_train_precision")
+            self.train_mode = m
+            self.train_f16 = m != 0   # the backward runs on the f16 kernels (f16 dy buffers; mode 2: hi and lo)
 
     def update_trunk_params(self, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b):
         """Refresh the training kernels' conv / BatchNorm parameters from device tensors stacked over the sub-bands."""
@@ -333,8 +339,9 @@ class HipEncoder:
             dpool = dpool.contiguous()
             W2 = W1 // 4
             st = (dpool.shape[1] * W2, 64 * self.freq_dim * W2, self.freq_dim * W2)
-            if getattr(self, "train_f16", False):   # the f16 dgrad kernel's operand: channel-minor halves
-                dy = torch.empty(self.n_sub, B, self.split // self.sub, W1, 64, device=dev, dtype=torch.float16)
+            if getattr(self, "train_f16", False):   # the f16 dgrad kernel's operand: channel-minor halves (f16x3: hi, then lo)
+                dy = torch.empty((2,) * (self.train_mode == 2) + (self.n_sub, B, self.split // self.sub, W1, 64), device=dev,
+                                 dtype=torch.float16)
             else:
                 dy = torch.empty(self.n_sub, B, 64, self.split // self.sub, W1, device=dev)
             dbn = torch.empty(self.n_sub, 64, 2, device=dev)
@@ -494,9 +501,10 @@ class MixingStyleEncoder(nn.Module):
         # (see _HipTrunk; 52 ms vs 98 ms per 72-clip step); "torch" = everything on PyTorch-ROCm autograd
         # "hip-strict" = as "hip", but raise instead of warning when a call cannot take the hand-written trunk
         self.train_backend = "hip"
-        # operand precision of the hand-written training trunk: "fp32" (exact), "f16" (float16 operands, fp32 accumulation:
-        # the reference's --use_amp arithmetic, see include/mst.h mst_encoder_set_train_precision), or "auto" = f16 inside
-        # `torch.autocast(dtype=float16)` (what src/train.py:251 turns on), fp32 otherwise
+        # precision of the hand-written training trunk: "fp32" (exact), "f16" (float16 operands, fp32 accumulation:
+        # the reference's --use_amp arithmetic, see include/mst.h mst_encoder_set_train_precision), "f16x3" (the same
+        # kernels with 3-term split-precision operands: fp32-equivalent), or "auto" = f16 inside `torch.autocast(dtype=float16)`
+        # (what src/train.py:251 turns on), fp32 otherwise
         self.train_precision = "auto"
         self._warned = set()
 
@@ -519,19 +527,20 @@ class MixingStyleEncoder(nn.Module):
         if self._hip_train is None:
             self._hip_train = HipEncoder(self, "fp32")
         enc = self._hip_train
-        if self.train_precision not in ("fp32", "f16", "auto"):
-            raise ValueError("train_precision must be 'fp32', 'f16' or 'auto'")
-        want_f16 = self.train_precision == "f16" or (
-            self.train_precision == "auto" and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16)
-        if want_f16 and enc.sub != 2:
-            why = f"split_size={ae.split_size}: the f16-operand training kernels cover 20-mel sub-bands; the trunk stays fp32"
-            if self.train_precision == "f16":
-                raise RuntimeError("MixingStyleEncoder.train_precision='f16': " + why)
+        if self.train_precision not in ("fp32", "f16", "f16x3", "auto"):
+            raise ValueError("train_precision must be 'fp32', 'f16', 'f16x3' or 'auto'")
+        want = self.train_precision
+        if want == "auto":
+            want = "f16" if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16 else "fp32"
+        if want != "fp32" and enc.sub != 2:
+            why = f"split_size={ae.split_size}: the f16 training kernels cover 20-mel sub-bands; the trunk stays fp32"
+            if self.train_precision != "auto":
+                raise RuntimeError(f"MixingStyleEncoder.train_precision='{self.train_precision}': " + why)
             if why not in self._warned:
                 self._warned.add(why)
                 warnings.warn("MixingStyleEncoder under autocast: " + why, RuntimeWarning, stacklevel=3)
-            want_f16 = False
-        enc.set_train_precision(want_f16)
+            want = "fp32"
+        enc.set_train_precision(want)
         cn = ae.subnet_cnns
         st = lambda f: torch.stack([f(c) for c in cn])  # noqa: E731
         flat = fe.film_head(fe.feature_mlp(mixing_features))

@@ -12,7 +12,7 @@ B, T = int(os.environ.get("B", 72)), 441000
 torch.manual_seed(0)
 model = MixingStyleEncoder(44100, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).cuda().train()
 model.train_backend = os.environ.get("TRAIN_BACKEND", "hip")   # "torch": encoder fwd/bwd on PyTorch-ROCm/MIOpen
-model.train_precision = os.environ.get("TRAIN_PRECISION", "fp32")   # "f16": float16 operands in the hand-written trunk
+model.train_precision = os.environ.get("TRAIN_PRECISION", "fp32")   # "f16" / "f16x3": see MixingStyleEncoder.train_precision
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
 fe = MixingFeatureExtractor()
 crit = InfoNCELoss(0.1)

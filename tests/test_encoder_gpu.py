@@ -306,7 +306,7 @@ def test_train_mode_forward_batch_statistics(T, B):
     assert (emb - e_eval).abs().max().item() > 1e-3 * e_eval.abs().max().item()   # it is NOT the eval forward
 
 
-@pytest.mark.parametrize("precision", ["fp32", "f16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16", "f16x3"])
 def test_results_do_not_depend_on_workspace_contents(precision):
     """Every slot of the activation workspace that a kernel reads must have been written by a kernel of the same step: with
     the workspace filled with 0xFF bytes (fp32 NaN, int64 -1) before each forward, the eval embeddings and a training
@@ -517,7 +517,7 @@ def test_train_mode_backward_of_pool_relu_film_batchnorm():
     close(dfilm.cpu(), film.grad, 2e-4)
 
 
-@pytest.mark.parametrize("cfgname", ["default", "baseline_sh"])
+@pytest.mark.parametrize("cfgname", ["default", "baseline_sh", "default-f16x3"])
 def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgname):
     """`train_backend="hip"` (conv trunk forward + backward in libmst.so) against PyTorch autograd of the same modules
     evaluated in FLOAT64: loss, every parameter gradient, running statistics.  Almost all gradients agree to ~2e-6.  Isolated
@@ -528,8 +528,10 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgnam
     check is: every tensor within 5e-2, at least 95 % of them within 1e-4, and no more outliers than PyTorch fp32 has + 3.
     Dropout off (p = 0) for the comparison; with p = 0.3 the native forward must agree with the mask it is given."""
     import copy
-    cfg = cases.CFG_DEFAULT if cfgname == "default" else cases.CFG_BASELINE_SH   # the reference's scripts/train_baseline.sh
+    cfg = cases.CFG_BASELINE_SH if cfgname == "baseline_sh" else cases.CFG_DEFAULT   # baseline_sh: the reference's scripts/train_baseline.sh
     model, sd = build_model(cfg)
+    if cfgname.endswith("f16x3"):   # all convolution-shaped products on 3-term split-precision f16: held to the SAME bar as the fp32 kernels
+        model.train_precision = "f16x3"
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
