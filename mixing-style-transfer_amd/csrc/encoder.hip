@@ -1535,6 +1535,7 @@ struct ApplyParams {
   const float* f16_scale;   // [B][nsub][2] = (s, 1/s)
   int raw_cols;             // layer 2: valid columns of the convolution output plane
   _Float16* out_l16;        // split-precision training forward: the low part (v * s - hi) next to out_h16
+  int pool_h;               // layer 1 on 2 x 40 tiles: 1 = MaxPool2d((1, 5)) (16-mel sub-bands: two 1 x 5 windows per 2 x 5 block), else (2, 5)
 };
 
 template <int LAYER, int SUB>
@@ -1573,18 +1574,26 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
     for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
   }
   if constexpr (LAYER == 1) {
+    const int nh = (SUB == 2 && p.pool_h == 1) ? 2 : 1;   // pool height 1 on the 2-row tiles: one window per tile row
 #pragma unroll
-    for (int wv = 0; wv < C::WPG; ++wv) {
+    for (int wv = 0; wv < C::WPG; ++wv)
+#pragma unroll
+    for (int hr = 0; hr < (SUB == 2 ? 2 : 1); ++hr) {
+      if (hr >= nh) continue;
       float m = 0.f;
 #pragma unroll
-      for (int pos = 0; pos < C::WIN; ++pos) m = fmaxf(m, fmaf(v[wv * C::WIN + pos], ac.x, ac.y));
+      for (int pos = 0; pos < C::WIN; ++pos) {
+        const bool mine = nh == 1 || pos / 5 == hr;
+        m = mine ? fmaxf(m, fmaf(v[wv * C::WIN + pos], ac.x, ac.y)) : m;
+      }
       const int pc = 4 * C::WPG * tc + C::WPG * g + wv;
-      if (pc < p.out_cols) {
-        const size_t o = ((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + tr) * p.out_cols + pc;
+      const int prow = nh == 1 ? tr : 2 * tr + hr;
+      if (pc < p.out_cols && prow < p.out_rows) {
+        const size_t o = ((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + prow) * p.out_cols + pc;
         const float v = p.mask ? (p.mask[o] ? m * p.mask_scale : 0.f) : m;
         p.out[o] = v;
         if (p.out_h16) {
-          const size_t o16 = ((((size_t)clip * p.nsub + band) * p.out_rows + tr) * p.out_cols + pc) * 32 + ch;
+          const size_t o16 = ((((size_t)clip * p.nsub + band) * p.out_rows + prow) * p.out_cols + pc) * 32 + ch;
           const float vs = v * p.f16_scale[((size_t)clip * p.nsub + band) * 2];
           const _Float16 h = (_Float16)vs;
           p.out_h16[o16] = h;
@@ -1629,6 +1638,7 @@ struct ApplyBwdParams {
   // NULL = 1), and layer 2's dy goes out as f16, channel-minor [band][clip][row][col][64] (conv2_dgrad_f16_kernel's operand)
   const float* in_scale;
   _Float16* dy_h16;
+  int pool_h;              // layer 1 on 2 x 40 tiles: 1 = pooling windows of 1 x 5 (see ApplyParams::pool_h)
   int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
   double count;
   int chunks;              // pass A: blocks per (clip, band)
@@ -1658,6 +1668,29 @@ __device__ __forceinline__ void unit_df(const ApplyBwdParams& p, const float (&v
   const float* dpb = p.dpool + clip * p.dp_clip + band * p.dp_band + ch * p.dp_ch;
   const float sin = p.in_scale ? p.in_scale[0] : 1.0f;
   constexpr int NW = LAYER == 1 ? C::WPG : 1, WIN = LAYER == 1 ? C::WIN : NV;
+  if (LAYER == 1 && SUB == 2 && p.pool_h == 1) {   // MaxPool2d((1, 5)) on the 2-row tiles: windows = the 5 columns of ONE tile row
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv)
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr) {
+        float m = 0.f;
+        int am = -1;
+#pragma unroll
+        for (int pos = 0; pos < 5; ++pos) {
+          const int e = wv * WIN + 5 * hr + pos;
+          const float f = fmaf(v[e], ac.x, ac.y);
+          if (f > m) m = f, am = e;
+        }
+        const int pr = 2 * tr + hr, pc = 4 * C::WPG * tc + C::WPG * g + wv;
+        const float d = (am >= 0 && pr < p.dp_rows && pc < p.dp_cols) ? dpb[(size_t)pr * p.dp_cols + pc] * sin : 0.f;
+#pragma unroll
+        for (int pos = 0; pos < 5; ++pos) {
+          const int e = wv * WIN + 5 * hr + pos;
+          df[e] = (e == am) ? d : 0.f;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int wv = 0; wv < NW; ++wv) {
     float m = 0.f;
@@ -2504,8 +2537,8 @@ int mst_encoder_set_precision(mst_encoder* e, int conv1_f16x3) {
 
 int mst_encoder_set_train_precision(mst_encoder* e, int f16_operands) {
   MST_REQUIRE(e, "mst_encoder_set_train_precision: NULL encoder");
-  MST_REQUIRE(f16_operands == 0 || ((f16_operands == 1 || f16_operands == 2) && e->sub == 2),
-              "mst_encoder_set_train_precision: modes 1 (f16 operands) and 2 (split-precision forward) need the default 20-mel sub-bands (pool height 2)");
+  MST_REQUIRE(f16_operands == 0 || ((f16_operands == 1 || f16_operands == 2) && (e->sub == 2 || e->cfg.split_size % 2 == 0)),
+              "mst_encoder_set_train_precision: modes 1 (f16 operands) and 2 (split precision) need 2-row conv1 tiles (20-mel sub-bands, or an even split_size below 20)");
   if (f16_operands && !e->w2dfrag16) {
     const int ns = e->cfg.n_subbands;
     bool ok = hipMalloc(&e->w2dfrag16, (size_t)ns * 8 * kF16Steps * 2 * 2 * 64 * 8 * sizeof(_Float16)) == hipSuccess;   // room for hi + lo
@@ -2705,8 +2738,9 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   TrainLayout T{};
   T.base = ws_layout(e, B, frames);
   const int ns = e->cfg.n_subbands;
-  const int tcols1 = e->sub == 2 ? 40 : 80;                    // conv1 tiles: SUB rows x 40 / 80 columns, ALL columns (statistics)
-  T.tr1 = e->H1, T.tc1 = (frames + tcols1 - 1) / tcols1;
+  const bool two_row = e->sub == 2 || train_fwd16(e);          // the f16 kernels tile 16-mel sub-bands like 20-mel ones: 2 x 40
+  const int tcols1 = two_row ? 40 : 80;                        // conv1 tiles: 2 x 40 or 1 x 80, ALL columns (statistics)
+  T.tr1 = two_row ? e->cfg.split_size / 2 : e->H1, T.tc1 = (frames + tcols1 - 1) / tcols1;
   T.tr2 = (e->H1 + 7) / 8, T.tc2 = (T.base.W1 + 7) / 8;      // conv2 tiles: 8 x 8, ALL rows
   size_t o = T.base.total;
   auto take = [&](size_t bytes) {
@@ -2848,7 +2882,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       ap.out_h16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_h16), ap.f16_scale = fsc;
       if (e->train_f16 == 2) ap.out_l16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_l16);
     }
-    if (e->sub == 2) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
+    ap.pool_h = e->sub;   // 2 x 40 tiles with 16-mel sub-bands (f16 modes): MaxPool2d((1, 5))
+    if (e->sub == 2 || train_fwd16(e)) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     else hipLaunchKernelGGL((apply_kernel<1, 1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -3002,6 +3037,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
     p.dy_acc = dy ? nullptr : reinterpret_cast<float*>(ws + T.y1);
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn1), p.bn_w = e->bn1w, p.bn_b = e->bn1b;
     p.dp_rows = e->H1, p.dp_cols = L.W1, p.tiles_r = T.tr1, p.tiles_c = T.tc1;
+    p.pool_h = e->sub;
     p.rows = e->cfg.split_size, p.cols = frames, p.goff = 0, p.boff = 32;
     p.count = (double)B * e->cfg.split_size * frames;
   } else {

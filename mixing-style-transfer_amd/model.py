@@ -532,8 +532,8 @@ class MixingStyleEncoder(nn.Module):
         want = self.train_precision
         if want == "auto":
             want = "f16" if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16 else "fp32"
-        if want != "fp32" and enc.sub != 2:
-            why = f"split_size={ae.split_size}: the f16 training kernels cover 20-mel sub-bands; the trunk stays fp32"
+        if want != "fp32" and enc.sub != 2 and ae.split_size % 2:
+            why = f"split_size={ae.split_size}: the f16 training kernels need an even split_size; the trunk stays fp32"
             if self.train_precision != "auto":
                 raise RuntimeError(f"MixingStyleEncoder.train_precision='{self.train_precision}': " + why)
             if why not in self._warned:
