@@ -47,6 +47,10 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--train-backend", choices=["hip", "torch"], default="hip",
                     help="hip: conv trunk forward + backward in libmst.so (default); torch: PyTorch-ROCm autograd")
+    ap.add_argument("--train-precision", choices=["fp32", "f16x3", "f16"], default="fp32",
+                    help="precision of the hand-written conv trunk: fp32 = exact fp32 MFMA; f16x3 = 3-term split-precision f16, "
+                         "fp32-equivalent gradients at about twice the speed; f16 = float16 operands with fp32 accumulation (the "
+                         "arithmetic of the reference's --use_amp step)")
     a = ap.parse_args(argv)
     sr = 44100
     if a.synthetic:
@@ -59,6 +63,7 @@ def main(argv=None):
                     collate_fn=ingest.pcm_collate_fn, pin_memory=True)
     model = MixingStyleEncoder(sr, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).to(dev).train()
     model.train_backend = a.train_backend
+    model.train_precision = a.train_precision
     fe = MixingFeatureExtractor(sr, 1024, 256, 128)
     crit = InfoNCELoss(0.1)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr)

@@ -11,10 +11,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_example_training_loop_learns(tmp_path):
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16"])
+def test_example_training_loop_learns(tmp_path, precision):
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import train_contrastive as tc
     losses = tc.main(["--shards", str(tmp_path / "shards"), "--synthetic", "6", "--track-seconds", "3.0",
-                      "--clip-seconds", "1.0", "--batch-size", "6", "--steps", "12", "--lr", "3e-4"])
+                      "--clip-seconds", "1.0", "--batch-size", "6", "--steps", "12", "--lr", "3e-4", "--train-precision", precision])
     assert len(losses) == 12 and all(l == l and l < 10 for l in losses)
     assert sum(losses[-3:]) / 3 < sum(losses[:3]) / 3, losses   # 6 songs x 2 segments: the loss must go down
