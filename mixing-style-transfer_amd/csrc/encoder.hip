@@ -1040,10 +1040,11 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
                                                                   const h16x8* __restrict__ in_lo,
                                                                   const h16x8* __restrict__ wfrag16) {
   constexpr int MT = 4, NT = 4, NCH = 4, PR = 14, PC = 14, NPOS = PR * PC;
-  constexpr int WV = kF16Steps * NT * 2 * 64;         // h16x8 vectors per weight chunk (6656 = 13 per thread)
-  constexpr int NWF = WV / kConvThreads;
+  constexpr int HLW = TERMS == 3 ? 2 : 1;             // the fragment buffer holds hi and lo; TERMS = 1 stages the hi vectors only
+  constexpr int WVG = kF16Steps * NT * 2 * 64;        // h16x8 vectors per weight chunk in global memory (hi/lo interleaved per (step, nt))
+  constexpr int WV = kF16Steps * NT * HLW * 64;       // ... staged into LDS (6656 = 13 per thread, or 3328)
+  constexpr int NWF = (WV + kConvThreads - 1) / kConvThreads;
   constexpr int NPF = (NPOS + 63) / 64;               // position vectors per lane (hi and lo each)
-  static_assert(WV % kConvThreads == 0, "weight chunk must split evenly");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1083,9 +1084,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
   h16x8 wreg[NWF], ph[NPF], pl[NPF];
   auto prefetch = [&](int q, const Tile& t) __attribute__((always_inline)) {
     const int chunk = q % NCH;
-    const h16x8* wsrc = wfrag16 + ((size_t)t.band * NCH + chunk) * WV;
+    const h16x8* wsrc = wfrag16 + ((size_t)t.band * NCH + chunk) * WVG;
 #pragma unroll
-    for (int i = 0; i < NWF; ++i) wreg[i] = wsrc[tid + kConvThreads * i];
+    for (int i = 0; i < NWF; ++i) {
+      const int k = min(tid + kConvThreads * i, WV - 1);
+      wreg[i] = wsrc[HLW == 2 ? k : ((k >> 6) * 2) * 64 + (k & 63)];
+    }
     const int row0 = 8 * t.tr - 3, col0 = 8 * t.tc - 3;
     const size_t plane = ((size_t)t.clip * p.nsub + t.band) * p.in_rows;
 #pragma unroll
@@ -1115,8 +1119,10 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
   if (nq > 0) prefetch(0, nxt);
   for (int q = 0; q < nq; ++q) {
     __syncthreads();  // every wave is done with the previous chunk's weights
+    if (!(p.row_off & 2))   // (p.row_off: timing-experiment bits of MST_CONV2_DBG -- 1 no MFMA, 2 no weight staging, 4 no raw store; 0 in production)
 #pragma unroll
-    for (int i = 0; i < NWF; ++i) wres[tid + kConvThreads * i] = wreg[i];
+    for (int i = 0; i < NWF; ++i)
+      if (WV % kConvThreads == 0 || tid + kConvThreads * i < WV) wres[tid + kConvThreads * i] = wreg[i];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = lane + 64 * i;
@@ -1146,8 +1152,8 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
         h16x8 ah[MTX], al[MTX], bh[NT], bl[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          bh[n] = wres[((st * NT + n) * 2 + 0) * 64 + lane];
-          if (TERMS == 3) bl[n] = wres[((st * NT + n) * 2 + 1) * 64 + lane];
+          bh[n] = wres[((st * NT + n) * HLW + 0) * 64 + lane];
+          if (TERMS == 3) bl[n] = wres[((st * NT + n) * HLW + 1) * 64 + lane];
         }
 #pragma unroll
         for (int t = 0; t < MTX; ++t) {
@@ -1168,9 +1174,11 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     };
     const bool low_rows = MODE == 1 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
                           8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;
-    if (MODE == 1 && low_rows) ksteps(std::integral_constant<int, 2>{});
-    else ksteps(std::integral_constant<int, MT>{});
-    if (MODE == 1 && chunk == NCH - 1 && cur.valid) {
+    if (!(p.row_off & 1)) {
+      if (MODE == 1 && low_rows) ksteps(std::integral_constant<int, 2>{});
+      else ksteps(std::integral_constant<int, MT>{});
+    }
+    if (MODE == 1 && chunk == NCH - 1 && cur.valid && !(p.row_off & 4)) {
       const int j = lane & 15, g = lane >> 4;
       if (cur.band != st_band) {
         if (st_band >= 0) flush_stats<NT, 64>(st, p.stats, st_band, lane);
@@ -2919,6 +2927,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       }
       cp.f16_scale = reinterpret_cast<const float*>(ws + T.t_f16scale);
       cp.f16_winv = e->f16_winv2;
+      cp.row_off = getenv("MST_CONV2_DBG") ? atoi(getenv("MST_CONV2_DBG")) : 0;   // timing experiments (results are wrong)
       const h16x8* ih = reinterpret_cast<const h16x8*>(ws + T.t_pool1_h16);
       const h16x8* wf2 = reinterpret_cast<const h16x8*>(e->w2frag16);
       if (e->train_f16 == 2)
