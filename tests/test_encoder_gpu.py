@@ -389,6 +389,48 @@ def test_f16_training_modes_at_config5_geometry(precision):
     assert np.median(e) < tol_med and e.max() < tol_max, max(errs)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16"])
+@pytest.mark.parametrize("B", [1, 9])
+def test_training_at_the_minimum_clip_length(B, precision):
+    """20 frames (the shortest clip the trunk accepts: W1 = 4, W2 = 1 -- single, partial tiles in every kernel) with a batch of 1
+    (one ragged 8-clip group) and of 9 (a full group + a group of one): loss and gradients against float64 autograd of the
+    torch modules (fp32 / f16x3: 1e-3 norm-wise per tensor -- tiny planes make single near-tie pooling decisions visible; f16:
+    a sanity bound only -- float16 operands under batch statistics of a few hundred positions are 10-20 % away from fp32
+    arithmetic here; its parity proper is the oracle test with the same roundings)."""
+    import copy
+    cfg = cases.CFG_DEFAULT
+    model, _ = build_model(cfg)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    ref64 = copy.deepcopy(model).double()
+    model.train(), ref64.train()
+    model.train_backend, ref64.train_backend, model.train_precision = "hip-strict", "torch", precision
+    T = 19 * 256
+    x = torch.stack([cases.synth_clip(c % 4, 44100)[:, 20000:20000 + T] * (1.0 + 0.2 * (c // 4)) for c in range(B)], 0).cuda()
+    g = torch.Generator().manual_seed(21)
+    feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
+    R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
+    assert lm.shape[-1] == 20
+    la = (model.forward_from_logmel(lm, feats) * R).sum()
+    lc = (ref64.forward_from_logmel(lm.double(), feats.double()) * R.double()).sum()
+    la.backward(), lc.backward()
+    tol = 1e-3 if precision != "f16" else 0.5
+    assert abs(la.item() - lc.item()) <= min(tol, 0.1) * abs(lc.item()) + 1e-6, (la.item(), lc.item())
+    worst = (0.0, "")
+    for (n, pa), (_, pc) in zip(model.named_parameters(), ref64.named_parameters()):
+        assert pa.grad is not None and torch.isfinite(pa.grad).all(), n
+        den = pc.grad.abs().max().item()
+        if den < 1e-9 or n.endswith(("conv1.bias", "conv2.bias", "attention.2.bias")):
+            continue
+        worst = max(worst, ((pa.grad.double() - pc.grad).abs().max().item() / den, n))
+    print(f"B={B}, 20 frames, {precision}: worst gradient error vs float64 autograd {worst[0]:.2e} ({worst[1]})")
+    parity.note(f"training at 20 frames, B={B}, {precision}: worst norm-wise gradient error vs float64 autograd", worst=float(worst[0]))
+    assert worst[0] < tol, worst
+
+
 def _stacked_trunk_params(model):
     cn = model.audio_encoder.subnet_cnns
     st = lambda f: torch.stack([f(c) for c in cn]).detach()  # noqa: E731
