@@ -174,9 +174,10 @@ int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int f
  * 0 (default): exact fp32 MFMA.  1: float16 operands, fp32 accumulation -- the arithmetic of the reference's `--use_amp`
  * step (autocast + GradScaler, src/train.py:251-262, src/params.py:71; BASELINE configs[4]): both operands of every
  * convolution-shaped product are rounded to f16 (forward y = conv(f16 x, f16 w); input gradient conv^T(f16 dy, f16 w);
- * weight gradient corr(f16 x, f16 dy)); BatchNorm statistics, FiLM, pooling, their backward, all reductions and the master
- * weights stay fp32.  Every rounded tensor is first multiplied by an exact power of two chosen on the device (weights per
- * output channel; pool1 per band from a bound on its values; the gradients by one factor per backward pass from
+ * weight gradient corr(f16 x, f16 dy)) and the convolution outputs are STORED as f16 (as autocast's are; BatchNorm's batch
+ * statistics are those of the stored values); the BatchNorm / FiLM / pooling arithmetic, their backward, all reductions and
+ * the master weights stay fp32.  Every rounded tensor is first multiplied by an exact power of two chosen on the device (weights per
+ * output channel; pool1 and the stored conv outputs per band from bounds on their values; the gradients by one factor per backward pass from
  * max |d pool_in| -- the internal equivalent of the reference's loss scale) and the factor is divided out in fp32, so neither
  * f16's ceiling nor its subnormals are reached; no host synchronisation.  Needs 20-mel sub-bands.
  * 2: the same kernels with THREE-TERM SPLIT PRECISION -- every operand is a pair hi + lo of float16 (22 significant bits),

@@ -188,7 +188,36 @@ struct ConvParams {
   // conv1_resident_kernel<2> only: 1 = MaxPool2d((1, 5)) on its 2 x 40 tiles (16-mel sub-bands: split // 10 == 1) -- the
   // lane's 10 accumulator positions are two 1 x 5 windows, one per tile row, instead of one 2 x 5 window; 0 / 2 = (2, 5)
   int pool_h;
+  // f16 training (mode 1): the raw output is STORED as float16 times the band's power-of-two scale y_scale[band][2] = (s, 1/s)
+  // (yraw16, same accumulator-order layout) -- the conv outputs of the reference's autocast step are half tensors too --
+  // and the batch statistics are those of the stored values.  NULL: fp32 yraw.
+  _Float16* yraw16;
+  const float* y_scale;
 };
+
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+// one lane-unit (NV accumulator slots) of the raw convolution output: fp32, or (y_scale != NULL) float16 times the band's scale
+template <int NV>
+__device__ __forceinline__ void load_unit(const void* yraw, const float* y_scale, int band, size_t unit, float (&v)[NV]) {
+  if (y_scale) {   // kernel-uniform
+    const float inv = y_scale[band * 2 + 1];
+    const h16x4* s = reinterpret_cast<const h16x4*>(yraw) + unit * (NV / 4);
+#pragma unroll
+    for (int t = 0; t < NV / 4; ++t) {
+      const h16x4 q = s[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * t + r] = (float)q[r] * inv;
+    }
+  } else {
+    const f32x4* s = reinterpret_cast<const f32x4*>(yraw) + unit * (NV / 4);
+#pragma unroll
+    for (int t = 0; t < NV / 4; ++t) {
+      const f32x4 q = s[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
+    }
+  }
+}
 
 // fold a lane's running (sum, sum of squares) of N-tile n over the 4 lane groups and add them to stats[band][ch][2]
 template <int NT, int COUT>
@@ -960,24 +989,30 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
     }
     if constexpr (MODE == 1) {
       const int j = lane & 15, g = lane >> 4;
-      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) *
-                               (size_t)(NT * 64 * 4 * MT);
+      const size_t unit0 = ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) * (size_t)(NT * 64);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const float b = p.bias[cur.band * C::COUT + n * 16 + j];
         const float wi = p.f16_winv[cur.band * C::COUT + n * 16 + j];   // undo the weight pre-scale (exact power of two)
-        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+        const size_t unit = unit0 + (size_t)(n * 64 + lane);
+        const float sy = p.yraw16 ? p.y_scale[cur.band * 2] : 1.f, isy = p.yraw16 ? p.y_scale[cur.band * 2 + 1] : 1.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
+          h16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] = fmaf(v[r], wi, b);
+            if (p.yraw16) {   // the value that is stored, and that the statistics are taken of
+              h[r] = to_f16_sat(v[r] * sy);
+              v[r] = (float)h[r] * isy;
+            }
             const int e = 4 * t + r, wv = e / C::WIN, pos = e % C::WIN;
             const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
             if (col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
-          dst[t] = v;
+          if (p.yraw16) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
+          else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
         }
       }
     } else {
@@ -1185,23 +1220,29 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
         st_band = cur.band;
       }
       const float inv_s = p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2 + 1] : 1.0f;
-      float* yb = p.yraw + ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) *
-                               (size_t)(NT * 64 * 4 * MT);
+      const size_t unit0 = ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) * (size_t)(NT * 64);
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const float b = p.bias[cur.band * 64 + n * 16 + j];
         const float wi = inv_s * p.f16_winv[cur.band * 64 + n * 16 + j];   // input range scale and weight pre-scale, exact powers of two
-        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+        const size_t unit = unit0 + (size_t)(n * 64 + lane);
+        const float sy = p.yraw16 ? p.y_scale[cur.band * 2] : 1.f, isy = p.yraw16 ? p.y_scale[cur.band * 2 + 1] : 1.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
+          h16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] = fmaf(v[r], wi, b);
+            if (p.yraw16) {
+              h[r] = to_f16_sat(v[r] * sy);
+              v[r] = (float)h[r] * isy;
+            }
             const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
             if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
-          dst[t] = v;
+          if (p.yraw16) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
+          else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
         }
       }
     }
@@ -1430,6 +1471,7 @@ struct mst_encoder {
   int train_f16 = 0;
   void* w2dfrag16 = nullptr;  // conv2 input-gradient fragments, hi only: [nsub][8 chunks][13 steps][2 nt][lane][8]
   float *f16_wsc1 = nullptr, *f16_wsc2 = nullptr, *f16_wsc2d = nullptr, *f16_winv2d = nullptr;   // pre-scales 2^k and the dgrad inverse
+  float* w2norm = nullptr;    // [nsub][64] L1 norms of the conv2 filters (range bound of the stored f16 conv2 outputs, mode 1)
 };
 
 namespace {
@@ -1544,6 +1586,7 @@ struct ApplyParams {
   int raw_cols;             // layer 2: valid columns of the convolution output plane
   _Float16* out_l16;        // split-precision training forward: the low part (v * s - hi) next to out_h16
   int pool_h;               // layer 1 on 2 x 40 tiles: 1 = MaxPool2d((1, 5)) (16-mel sub-bands: two 1 x 5 windows per 2 x 5 block), else (2, 5)
+  const float* y_scale;     // non-NULL: yraw holds float16 times y_scale[band][0] (ConvParams::yraw16)
 };
 
 template <int LAYER, int SUB>
@@ -1561,25 +1604,30 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
   const int band = (int)(tile % p.nsub), clip = (int)(tile / p.nsub);
   const int j = lane & 15, g = lane >> 4, ch = n * 16 + j;
   const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
-  f32x4* src = reinterpret_cast<f32x4*>(p.yraw + (size_t)u * NV);
   float v[NV];
+  load_unit<NV>(p.yraw, p.y_scale, band, (size_t)u, v);
+  if constexpr (LAYER == 2) {   // slots that are no positions of the plane: keep them 0 for the backward pass (it reads every slot)
+    bool touched = false;
 #pragma unroll
-  for (int t = 0; t < C::MT; ++t) {
-    f32x4 q = src[t];
-    if constexpr (LAYER == 2) {
-      const int col0 = 8 * tc + 4 * (g & 1);
-      if (8 * tr + 4 * (g >> 1) + t >= p.raw_rows) {   // no such output row: keep the slot finite for the backward pass
-        q = f32x4{0.f, 0.f, 0.f, 0.f};
-        src[t] = q;
-      } else if (col0 + 3 >= p.raw_cols) {             // columns past the plane (the strip kernel never writes them)
+    for (int t = 0; t < C::MT; ++t) {
+      const bool no_row = 8 * tr + 4 * (g >> 1) + t >= p.raw_rows;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (col0 + r >= p.raw_cols) q[r] = 0.f;
-        src[t] = q;
+      for (int r = 0; r < 4; ++r)
+        if (no_row || 8 * tc + 4 * (g & 1) + r >= p.raw_cols) v[4 * t + r] = 0.f, touched = true;
+    }
+    if (touched) {
+#pragma unroll
+      for (int t = 0; t < C::MT; ++t) {
+        if (p.y_scale) {
+          h16x4 h;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[r] = (_Float16)(v[4 * t + r] * p.y_scale[band * 2]);   // exact: v came from h / s
+          reinterpret_cast<h16x4*>(p.yraw)[(size_t)u * C::MT + t] = h;
+        } else {
+          reinterpret_cast<f32x4*>(p.yraw)[(size_t)u * C::MT + t] = f32x4{v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+        }
       }
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
   }
   if constexpr (LAYER == 1) {
     const int nh = (SUB == 2 && p.pool_h == 1) ? 2 : 1;   // pool height 1 on the 2-row tiles: one window per tile row
@@ -1647,6 +1695,7 @@ struct ApplyBwdParams {
   const float* in_scale;
   _Float16* dy_h16;
   int pool_h;              // layer 1 on 2 x 40 tiles: 1 = pooling windows of 1 x 5 (see ApplyParams::pool_h)
+  const float* y_scale;    // non-NULL: yraw holds float16 times y_scale[band][0] (f16 training)
   int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
   double count;
   int chunks;              // pass A: blocks per (clip, band)
@@ -1738,14 +1787,8 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
     const float gb = p.bn_w[band * C::COUT + ch], bb = p.bn_b[band * C::COUT + ch];
     const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
     const size_t u = ((((size_t)clip * p.nsub + band) * p.tiles_r + tr) * p.tiles_c + tc) * NT + n;
-    const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (u * 64 + lane) * NV);
     float v[NV], df[NV];
-#pragma unroll
-    for (int t = 0; t < C::MT; ++t) {
-      const f32x4 q = src[t];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
-    }
+    load_unit<NV>(p.yraw, p.y_scale, band, u * 64 + lane, v);
     unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
@@ -2532,6 +2575,7 @@ void mst_encoder_destroy(mst_encoder* e) {
   (void)hipFree(e->w2frag16);
   (void)hipFree(e->w2dfrag16);
   (void)hipFree(e->f16_wsc1), (void)hipFree(e->f16_wsc2), (void)hipFree(e->f16_wsc2d), (void)hipFree(e->f16_winv2d);
+  (void)hipFree(e->w2norm);
   delete e;
 }
 
@@ -2552,6 +2596,7 @@ int mst_encoder_set_train_precision(mst_encoder* e, int f16_operands) {
     bool ok = hipMalloc(&e->w2dfrag16, (size_t)ns * 8 * kF16Steps * 2 * 2 * 64 * 8 * sizeof(_Float16)) == hipSuccess;   // room for hi + lo
     ok = ok && hipMalloc(&e->f16_wsc1, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_wsc2, (size_t)ns * 64 * 4) == hipSuccess;
     ok = ok && hipMalloc(&e->f16_wsc2d, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_winv2d, (size_t)ns * 32 * 4) == hipSuccess;
+    ok = ok && hipMalloc(&e->w2norm, (size_t)ns * 64 * 4) == hipSuccess;
     if (!ok) return mst::fail(MST_ENOMEM, "mst_encoder_set_train_precision: out of device memory");
   }
   e->train_f16 = f16_operands;
@@ -2739,7 +2784,7 @@ namespace {
 struct TrainLayout {
   WsLayout base;
   size_t y1, y2, stats1, stats2, bn1, bn2, dfilm_acc, dw_acc, total;
-  size_t t_pool1_h16, t_pool1_l16, t_f16scale, t_xmax, t_bscale, t_dyg1, t_dyg2;   // f16 training modes only (0 bytes otherwise)
+  size_t t_pool1_h16, t_pool1_l16, t_f16scale, t_xmax, t_bscale, t_dyg1, t_dyg2, t_ys1, t_ys2;   // f16 training modes only (0 bytes otherwise)
   int tr1, tc1, tr2, tc2;
 };
 TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
@@ -2756,8 +2801,9 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
     o += mst::align_up(bytes, 256);
     return at;
   };
-  T.y1 = take((size_t)B * ns * T.tr1 * T.tc1 * 2 * 64 * 20 * 4);
-  T.y2 = take((size_t)B * ns * T.tr2 * T.tc2 * 4 * 64 * 16 * 4);
+  const size_t ybytes = e->train_f16 == 1 ? 2 : 4;   // mode 1 stores the raw conv outputs as float16
+  T.y1 = take((size_t)B * ns * T.tr1 * T.tc1 * 2 * 64 * 20 * ybytes);
+  T.y2 = take((size_t)B * ns * T.tr2 * T.tc2 * 4 * 64 * 16 * ybytes);
   T.stats1 = take((size_t)ns * 32 * 2 * sizeof(mst::DetAcc));
   T.stats2 = take((size_t)ns * 64 * 2 * sizeof(mst::DetAcc));
   T.bn1 = take((size_t)ns * 32 * 8);
@@ -2769,6 +2815,8 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   T.t_pool1_l16 = take((e->train_f16 == 2 ? 1 : 0) * (size_t)B * ns * 32 * e->H1 * T.base.W1 * 2);   // its low part (split precision)
   T.t_f16scale = take(f * (size_t)B * ns * 2 * 4);
   T.t_xmax = take(f * (size_t)B * 4);
+  T.t_ys1 = take((e->train_f16 == 1 ? 1 : 0) * (size_t)ns * 2 * 4);              // range scales of the stored f16 conv outputs, [nsub][2]
+  T.t_ys2 = take((e->train_f16 == 1 ? 1 : 0) * (size_t)ns * 2 * 4);
   T.t_bscale = take(fb * 16);                                               // (s, 1/s) of the backward pass + the max |d pool_in| bits
   const size_t cgs = (size_t)((B + 7) / 8);                                 // d(conv output) as f16 in the weight gradients' operand layout
   const size_t hl = e->train_f16 == 2 ? 2 : 1;                              // split precision: hi and lo
@@ -2836,6 +2884,14 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     const int g = std::min(grid, ns * cp.sets_per_band);
     if (train_fwd16(e)) {   // f16 operands (mode 1) or 3-term split precision (mode 2), fp32 accumulate (encoder_f16train.inc)
       using C = CC<1, 2>;
+      unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);   // max |log-mel| per clip: bounds for the range scales
+      MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
+      hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, (long long)8 * e->cfg.n_mels * frames, xmax);
+      if (e->train_f16 == 1) {   // the raw output is stored as float16 times a per-band power of two
+        float* ys1 = reinterpret_cast<float*>(ws + T.t_ys1);
+        hipLaunchKernelGGL(f16_yscale_kernel, dim3(ns), dim3(64), 0, st, e->w1norm, e->c1b, 32, xmax, B, static_cast<const float*>(nullptr), ys1);
+        cp.yraw16 = reinterpret_cast<_Float16*>(y1), cp.y_scale = ys1;
+      }
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {
@@ -2880,15 +2936,13 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
                    B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr, frames};
     if (train_fwd16(e)) {   // range scale of conv2's f16 operand: one power of two per band from a bound on the pooled values
-      unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);
+      unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);   // (computed in front of conv1)
       float* fsc = reinterpret_cast<float*>(ws + T.t_f16scale);
-      MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
-      const long long npc = (long long)8 * e->cfg.n_mels * frames;
-      hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, npc, xmax);
       hipLaunchKernelGGL(f16_scale_band_kernel, dim3(ns), dim3(64), 0, st, aff1, e->w1norm, xmax, e->c1b,
                          (taps && taps->drop1_mask) ? taps->drop1_scale : 1.f, fsc, B, ns);
       ap.out_h16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_h16), ap.f16_scale = fsc;
       if (e->train_f16 == 2) ap.out_l16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_l16);
+      if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys1);
     }
     ap.pool_h = e->sub;   // 2 x 40 tiles with 16-mel sub-bands (f16 modes): MaxPool2d((1, 5))
     if (e->sub == 2 || train_fwd16(e)) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
@@ -2928,6 +2982,12 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       cp.f16_scale = reinterpret_cast<const float*>(ws + T.t_f16scale);
       cp.f16_winv = e->f16_winv2;
       cp.row_off = getenv("MST_CONV2_DBG") ? atoi(getenv("MST_CONV2_DBG")) : 0;   // timing experiments (results are wrong)
+      if (e->train_f16 == 1) {
+        float* ys2 = reinterpret_cast<float*>(ws + T.t_ys2);
+        hipLaunchKernelGGL(f16_yscale_kernel, dim3(ns), dim3(64), 0, st, e->w2norm, e->c2b, 64, static_cast<const unsigned*>(nullptr), B,
+                           cp.f16_scale, ys2);
+        cp.yraw16 = reinterpret_cast<_Float16*>(y2), cp.y_scale = ys2;
+      }
       const h16x8* ih = reinterpret_cast<const h16x8*>(ws + T.t_pool1_h16);
       const h16x8* wf2 = reinterpret_cast<const h16x8*>(e->w2frag16);
       if (e->train_f16 == 2)
@@ -2971,6 +3031,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
     ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64,
                    nullptr, nullptr, L.W1};
+    if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys2);
     hipLaunchKernelGGL((apply_kernel<2, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -3047,11 +3108,13 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn1), p.bn_w = e->bn1w, p.bn_b = e->bn1b;
     p.dp_rows = e->H1, p.dp_cols = L.W1, p.tiles_r = T.tr1, p.tiles_c = T.tc1;
     p.pool_h = e->sub;
+    if (e->train_f16 == 1) p.y_scale = reinterpret_cast<const float*>(ws + T.t_ys1);
     p.rows = e->cfg.split_size, p.cols = frames, p.goff = 0, p.boff = 32;
     p.count = (double)B * e->cfg.split_size * frames;
   } else {
     p.yraw = reinterpret_cast<const float*>(ws + T.y2), p.aff = reinterpret_cast<const float2*>(ws + L.aff2);
-    p.dy_acc = reinterpret_cast<float*>(ws + T.y2);   // layer 2: always kept in accumulator order as well (conv2 wgrad)
+    p.dy_acc = reinterpret_cast<float*>(ws + T.y2);   // layer 2: always kept in accumulator order as well (conv2 wgrad; fp32 mode only)
+    if (e->train_f16 == 1) p.y_scale = reinterpret_cast<const float*>(ws + T.t_ys2);
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn2), p.bn_w = e->bn2w, p.bn_b = e->bn2b;
     p.dp_rows = e->FD, p.dp_cols = L.W2, p.tiles_r = T.tr2, p.tiles_c = T.tc2;
     p.rows = e->H1, p.cols = L.W1, p.goff = 64, p.boff = 128;
@@ -3120,7 +3183,7 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
     hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 32), dim3(64), 0, st, conv1_w, 32, (long long)32 * 392, 392, 1, 0, 392,
                        e->f16_wsc1, e->f16_winv1, e->w1norm);
     hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 64), dim3(64), 0, st, conv2_w, 64, (long long)64 * 1568, 1568, 1, 0, 1568,
-                       e->f16_wsc2, e->f16_winv2, static_cast<float*>(nullptr));
+                       e->f16_wsc2, e->f16_winv2, e->w2norm);
     hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 32), dim3(64), 0, st, conv2_w, 32, (long long)64 * 1568, 49, 64, 1568, 49,
                        e->f16_wsc2d, e->f16_winv2d, static_cast<float*>(nullptr));
     const long long n1 = (long long)ns * 1 * kF16Steps * 2 * 512, n2 = (long long)ns * 4 * kF16Steps * 4 * 512,

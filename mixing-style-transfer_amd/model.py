@@ -553,12 +553,20 @@ class MixingStyleEncoder(nn.Module):
             B, Fr = logmel.shape[0], logmel.shape[-1]
             for stat, name, n in ((bn1, "bn1", B * ae.split_size * Fr), (bn2, "bn2", B * (ae.split_size // enc.sub) * (Fr // 5))):
                 mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * (n / max(n - 1, 1))
-                for i, c in enumerate(cn):
-                    bn = getattr(c, name)
-                    m = bn.momentum if bn.momentum is not None else 0.1
-                    bn.running_mean.mul_(1 - m).add_(mean[i], alpha=m)
-                    bn.running_var.mul_(1 - m).add_(var[i], alpha=m)
-                    bn.num_batches_tracked += 1
+                bns = [getattr(c, name) for c in cn]
+                moms = {bn.momentum if bn.momentum is not None else 0.1 for bn in bns}
+                if len(moms) == 1:   # one multi-tensor launch per update instead of 3 x n_sub tiny kernels
+                    m = moms.pop()
+                    for bufs, new in (([bn.running_mean for bn in bns], mean), ([bn.running_var for bn in bns], var)):
+                        torch._foreach_mul_(bufs, 1 - m)
+                        torch._foreach_add_(bufs, list(new.unbind(0)), alpha=m)
+                    torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+                else:
+                    for i, bn in enumerate(bns):
+                        m = bn.momentum if bn.momentum is not None else 0.1
+                        bn.running_mean.mul_(1 - m).add_(mean[i], alpha=m)
+                        bn.running_var.mul_(1 - m).add_(var[i], alpha=m)
+                        bn.num_batches_tracked += 1
         x = F.dropout(pool_in, cn[0].dropout2.p, self.training)
         return ae.attention_pooling(x)
 

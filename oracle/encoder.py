@@ -42,7 +42,7 @@ def _f16_operand(t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 
 
 def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int,
-                taps=None, f16_operands=False, bn_training=False) -> torch.Tensor:
+                taps=None, f16_operands=False, bn_training=False, f16_outputs=False) -> torch.Tensor:
     """model.py:127-157 for sub-band i.  x (B, 8, split, F) -> (B, 64, H', W').
     f16_operands: the arithmetic of the opt-in "f16" precision mode (and of the reference under `--use_amp` autocast,
     src/train.py:251-253, for the convolutions): conv inputs and weights rounded to float16, products and sums in fp32."""
@@ -55,6 +55,8 @@ def subband_cnn(sd, i: int, x: torch.Tensor, film: torch.Tensor, split_size: int
         if f16_operands:
             x, w = _f16_operand(x), _f16_operand(w, 1024.0)
         x = F.conv2d(x, w, sd[p + conv + ".bias"], padding=3)
+        if f16_outputs:   # f16 TRAINING mode: the convolution output is stored as float16 (as under torch.autocast), statistics of that
+            x = round_f16_ideal(x)
         if taps is not None and x.requires_grad:   # gradient checks: keep the convolution output and its gradient
             x.retain_grad()
             taps[f"{conv}_out_{i}"] = x
@@ -88,11 +90,12 @@ def attention_pool(sd, x: torch.Tensor) -> torch.Tensor:
 
 
 def encoder_from_logmel(sd, lm: torch.Tensor, feats: torch.Tensor, split_size=20, overlap=10,
-                        taps=None, f16_operands=False, bn_training=False) -> torch.Tensor:
+                        taps=None, f16_operands=False, bn_training=False, f16_outputs=False) -> torch.Tensor:
     """log-mel (B, 8, M, F), features (B, Fd) -> embeddings (B, E).  model.py:290-382,508-542."""
     film = film_params(sd, feats)
     nsub = n_subbands(lm.shape[2], split_size, overlap)
-    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps, f16_operands, bn_training)
+    outs = [subband_cnn(sd, i, lm[:, :, i * overlap:i * overlap + split_size, :], film, split_size, taps, f16_operands, bn_training,
+                        f16_outputs)
             for i in range(nsub)]
     cat = torch.cat(outs, dim=1)  # (B, nsub*64, H', W')
     flat = cat.reshape(cat.shape[0], cat.shape[1] * cat.shape[2], cat.shape[3])

@@ -5,11 +5,12 @@ src/params.py:71): its convolutions see float16 inputs and weights and accumulat
 gradients.  The hand-written f16 training kernels (`mst_encoder_set_train_precision(enc, 1)`, include/mst.h) define the
 same thing precisely: BOTH operands of every convolution-shaped product are rounded to float16 --
 
-    forward          y  = conv(r(x), r(w)) + b
+    forward          y  = r(conv(r(x), r(w)) + b)        (the output is stored as float16, as autocast's conv output is;
+                                                          BatchNorm's batch statistics are those of the stored values)
     input gradient   dx = conv^T(r(dy), r(w))
     weight gradient  dW = corr(r(x), r(dy))
 
--- and everything else is exact.  This module restates that as a `torch.autograd.Function`, to be evaluated in float64 on
+-- and everything else is exact (the rounding of y is transparent to the gradient, as a dtype cast is in autograd).  This module restates that as a `torch.autograd.Function`, to be evaluated in float64 on
 the CPU or the GPU by the tests: r() rounds to float16's 11 significant bits with an UNBOUNDED exponent, because the
 kernels multiply every tensor by an exact power of two before rounding (per-channel weight scale, per-band activation
 scale, one loss scale per backward pass) so that neither the 65504 ceiling nor the subnormals are reached.
@@ -28,7 +29,7 @@ class _F16OperandConv(torch.autograd.Function):
         xr, wr = round_f16_ideal(x), round_f16_ideal(w)
         ctx.save_for_backward(xr, wr)
         ctx.padding = padding
-        return F.conv2d(xr, wr, b, padding=padding)
+        return round_f16_ideal(F.conv2d(xr, wr, b, padding=padding))   # the output is STORED as float16 (gradient: straight through)
 
     @staticmethod
     def backward(ctx, dy):
