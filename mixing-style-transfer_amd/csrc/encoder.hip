@@ -1182,6 +1182,30 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     // single MFMAs inside one loop breaks the software pipeline.
     auto ksteps = [&](auto mtx_c) __attribute__((always_inline)) {
       constexpr int MTX = decltype(mtx_c)::value;
+      if constexpr (TERMS == 1 && MODE == 0) {   // the fragments of step st + 1 are read from LDS while the MFMAs of step st run (double-buffered
+                                    // registers; with the low parts of TERMS = 3, or the statistics of MODE 1, the second set does not fit the register file)
+        h16x8 a[2][MTX], b[2][NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[0][n] = wres[n * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < MTX; ++t) a[0][t] = phi[abase[t] + toff[0]];
+#pragma unroll
+        for (int st = 0; st < kF16Steps; ++st) {
+          const int cu = st & 1, nx = cu ^ 1;
+          if (st + 1 < kF16Steps) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[nx][n] = wres[((st + 1) * NT + n) * 64 + lane];
+#pragma unroll
+            for (int t = 0; t < MTX; ++t) a[nx][t] = phi[abase[t] + toff[st + 1]];
+          }
+#pragma unroll
+          for (int t = 0; t < MTX; ++t)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
+        }
+        return;
+      }
 #pragma unroll
       for (int st = 0; st < kF16Steps; ++st) {
         h16x8 ah[MTX], al[MTX], bh[NT], bl[NT];
