@@ -909,7 +909,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
   for (int s = s_begin; s < s_end; ++s) {
     cur = nxt;
     if (cur.band != cur_band) {
-      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
+      if (MODE >= 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
       __syncthreads();
       const h16x8* src = wfrag16 + (size_t)cur.band * WVEC;
       for (int k = tid; k < WVEC; k += kConvThreads) wres[k] = src[k];
@@ -987,7 +987,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
         __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
       }
     }
-    if constexpr (MODE == 1) {
+    if constexpr (MODE >= 1) {
       const int j = lane & 15, g = lane >> 4;
       const size_t unit0 = ((((size_t)cur.clip * p.nsub + cur.band) * p.acc_tr + cur.tr) * p.acc_tc + cur.tc) * (size_t)(NT * 64);
 #pragma unroll
@@ -995,7 +995,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
         const float b = p.bias[cur.band * C::COUT + n * 16 + j];
         const float wi = p.f16_winv[cur.band * C::COUT + n * 16 + j];   // undo the weight pre-scale (exact power of two)
         const size_t unit = unit0 + (size_t)(n * 64 + lane);
-        const float sy = p.yraw16 ? p.y_scale[cur.band * 2] : 1.f, isy = p.yraw16 ? p.y_scale[cur.band * 2 + 1] : 1.f;
+        const float sy = MODE == 2 ? p.y_scale[cur.band * 2] : 1.f, isy = MODE == 2 ? p.y_scale[cur.band * 2 + 1] : 1.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] = fmaf(v[r], wi, b);
-            if (p.yraw16) {   // the value that is stored, and that the statistics are taken of
+            if constexpr (MODE == 2) {   // the value that is stored, and that the statistics are taken of
               h[r] = to_f16_sat(v[r] * sy);
               v[r] = (float)h[r] * isy;
             }
@@ -1011,7 +1011,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
             const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
             if (col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
-          if (p.yraw16) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
+          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
           else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
         }
       }
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
       }
     }
   }
-  if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
+  if (MODE >= 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1122,8 +1122,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     const h16x8* wsrc = wfrag16 + ((size_t)t.band * NCH + chunk) * WVG;
 #pragma unroll
     for (int i = 0; i < NWF; ++i) {
-      const int k = min(tid + kConvThreads * i, WV - 1);
-      wreg[i] = wsrc[HLW == 2 ? k : ((k >> 6) * 2) * 64 + (k & 63)];
+      if constexpr (HLW == 2) {   // WV is a multiple of the block size: one base address + immediate offsets
+        wreg[i] = wsrc[tid + kConvThreads * i];
+      } else {
+        const int k = min(tid + kConvThreads * i, WV - 1);
+        wreg[i] = wsrc[((k >> 6) * 2) * 64 + (k & 63)];
+      }
     }
     const int row0 = 8 * t.tr - 3, col0 = 8 * t.tc - 3;
     const size_t plane = ((size_t)t.clip * p.nsub + t.band) * p.in_rows;
@@ -1154,7 +1158,6 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
   if (nq > 0) prefetch(0, nxt);
   for (int q = 0; q < nq; ++q) {
     __syncthreads();  // every wave is done with the previous chunk's weights
-    if (!(p.row_off & 2))   // (p.row_off: timing-experiment bits of MST_CONV2_DBG -- 1 no MFMA, 2 no weight staging, 4 no raw store; 0 in production)
 #pragma unroll
     for (int i = 0; i < NWF; ++i)
       if (WV % kConvThreads == 0 || tid + kConvThreads * i < WV) wres[tid + kConvThreads * i] = wreg[i];
@@ -1179,65 +1182,60 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     }
     // training forward, last tile row of a plane whose height is 8 k + 1 or 8 k + 2 (rows 8, 9 of 10): only M-tiles 0, 1 hold
     // rows that exist.  Two straight-line instantiations of the k-step loop, chosen per tile (wave-uniform): a branch around
-    // single MFMAs inside one loop breaks the software pipeline.
-    auto ksteps = [&](auto mtx_c) __attribute__((always_inline)) {
-      constexpr int MTX = decltype(mtx_c)::value;
-      if constexpr (TERMS == 1 && MODE == 0) {   // the fragments of step st + 1 are read from LDS while the MFMAs of step st run (double-buffered
-                                    // registers; with the low parts of TERMS = 3, or the statistics of MODE 1, the second set does not fit the register file)
-        h16x8 a[2][MTX], b[2][NT];
+    // single MFMAs inside one loop breaks the software pipeline.  (A macro, not a lambda: capturing the accumulator arrays
+    // by reference cost registers -- 34 spilled VGPRs in the eval instantiation.)
+#define MST_CONV2_F16_KSTEPS(MTX)                                                                                         \
+  _Pragma("unroll") for (int st = 0; st < kF16Steps; ++st) {                                                              \
+    h16x8 ah[MTX], al[MTX], bh[NT], bl[NT];                                                                               \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                                      \
+      bh[n] = wres[((st * NT + n) * HLW + 0) * 64 + lane];                                                                \
+      if (TERMS == 3) bl[n] = wres[((st * NT + n) * HLW + 1) * 64 + lane];                                                \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int t = 0; t < MTX; ++t) {                                                                     \
+      ah[t] = phi[abase[t] + toff[st]];                                                                                   \
+      if (TERMS == 3) al[t] = plo[abase[t] + toff[st]];                                                                   \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int t = 0; t < MTX; ++t)                                                                       \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                                    \
+        if (TERMS == 3) {                                                                                                 \
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);                          \
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);                          \
+        }                                                                                                                 \
+        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);                            \
+      }                                                                                                                   \
+  }
+    const bool low_rows = MODE >= 1 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
+                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;
+    if constexpr (TERMS == 1 && MODE == 0) {   // the fragments of step st + 1 are read from LDS while the MFMAs of step st run
+      // (double-buffered registers; with the low parts of TERMS = 3, or the statistics of the training modes, the second set
+      // does not fit the register file)
+      h16x8 a[2][MT], b[2][NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[0][n] = wres[n * 64 + lane];
+      for (int n = 0; n < NT; ++n) b[0][n] = wres[n * 64 + lane];
 #pragma unroll
-        for (int t = 0; t < MTX; ++t) a[0][t] = phi[abase[t] + toff[0]];
-#pragma unroll
-        for (int st = 0; st < kF16Steps; ++st) {
-          const int cu = st & 1, nx = cu ^ 1;
-          if (st + 1 < kF16Steps) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) b[nx][n] = wres[((st + 1) * NT + n) * 64 + lane];
-#pragma unroll
-            for (int t = 0; t < MTX; ++t) a[nx][t] = phi[abase[t] + toff[st + 1]];
-          }
-#pragma unroll
-          for (int t = 0; t < MTX; ++t)
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
-        }
-        return;
-      }
+      for (int t = 0; t < MT; ++t) a[0][t] = phi[abase[t] + toff[0]];
 #pragma unroll
       for (int st = 0; st < kF16Steps; ++st) {
-        h16x8 ah[MTX], al[MTX], bh[NT], bl[NT];
+        const int cu = st & 1, nx = cu ^ 1;
+        if (st + 1 < kF16Steps) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          bh[n] = wres[((st * NT + n) * HLW + 0) * 64 + lane];
-          if (TERMS == 3) bl[n] = wres[((st * NT + n) * HLW + 1) * 64 + lane];
+          for (int n = 0; n < NT; ++n) b[nx][n] = wres[((st + 1) * NT + n) * 64 + lane];
+#pragma unroll
+          for (int t = 0; t < MT; ++t) a[nx][t] = phi[abase[t] + toff[st + 1]];
         }
 #pragma unroll
-        for (int t = 0; t < MTX; ++t) {
-          ah[t] = phi[abase[t] + toff[st]];
-          if (TERMS == 3) al[t] = plo[abase[t] + toff[st]];
-        }
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int t = 0; t < MTX; ++t)
-#pragma unroll
-          for (int n = 0; n < NT; ++n) {
-            if (TERMS == 3) {
-              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[n], acc[t][n], 0, 0, 0);
-              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[n], acc[t][n], 0, 0, 0);
-            }
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[n], acc[t][n], 0, 0, 0);
-          }
+          for (int n = 0; n < NT; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
       }
-    };
-    const bool low_rows = MODE == 1 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
-                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;
-    if (!(p.row_off & 1)) {
-      if (MODE == 1 && low_rows) ksteps(std::integral_constant<int, 2>{});
-      else ksteps(std::integral_constant<int, MT>{});
+    } else if (MODE >= 1 && low_rows) {
+      MST_CONV2_F16_KSTEPS(2)
+    } else {
+      MST_CONV2_F16_KSTEPS(MT)
     }
-    if (MODE == 1 && chunk == NCH - 1 && cur.valid && !(p.row_off & 4)) {
+#undef MST_CONV2_F16_KSTEPS
+    if (MODE >= 1 && chunk == NCH - 1 && cur.valid) {
       const int j = lane & 15, g = lane >> 4;
       if (cur.band != st_band) {
         if (st_band >= 0) flush_stats<NT, 64>(st, p.stats, st_band, lane);
@@ -1250,7 +1248,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
         const float b = p.bias[cur.band * 64 + n * 16 + j];
         const float wi = inv_s * p.f16_winv[cur.band * 64 + n * 16 + j];   // input range scale and weight pre-scale, exact powers of two
         const size_t unit = unit0 + (size_t)(n * 64 + lane);
-        const float sy = p.yraw16 ? p.y_scale[cur.band * 2] : 1.f, isy = p.yraw16 ? p.y_scale[cur.band * 2 + 1] : 1.f;
+        const float sy = MODE == 2 ? p.y_scale[cur.band * 2] : 1.f, isy = MODE == 2 ? p.y_scale[cur.band * 2 + 1] : 1.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
@@ -1258,14 +1256,14 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             v[r] = fmaf(v[r], wi, b);
-            if (p.yraw16) {
+            if constexpr (MODE == 2) {
               h[r] = to_f16_sat(v[r] * sy);
               v[r] = (float)h[r] * isy;
             }
             const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
             if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
-          if (p.yraw16) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
+          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
           else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
         }
       }
@@ -1290,7 +1288,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
       }
     }
   }
-  if (MODE == 1 && st_band >= 0) flush_stats<NT, 64>(st, p.stats, st_band, lane);
+  if (MODE >= 1 && st_band >= 0) flush_stats<NT, 64>(st, p.stats, st_band, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2919,7 +2917,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 1>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3, 1>),
@@ -2930,7 +2928,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
       _Float16* none = nullptr;
       if (e->train_f16 == 2) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
-      else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
+      else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
     } else if (e->sub == 2) {
       using C = CC<1, 2>;
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
@@ -2996,7 +2994,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       constexpr size_t lds = (size_t)(kF16Steps * 4 * 2 * 64 + kConvWaves * 2 * 14 * 14) * 16;
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<1, 1>),
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<1, 2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv2_f16x3_kernel<3, 1>),
@@ -3005,7 +3003,6 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       }
       cp.f16_scale = reinterpret_cast<const float*>(ws + T.t_f16scale);
       cp.f16_winv = e->f16_winv2;
-      cp.row_off = getenv("MST_CONV2_DBG") ? atoi(getenv("MST_CONV2_DBG")) : 0;   // timing experiments (results are wrong)
       if (e->train_f16 == 1) {
         float* ys2 = reinterpret_cast<float*>(ws + T.t_ys2);
         hipLaunchKernelGGL(f16_yscale_kernel, dim3(ns), dim3(64), 0, st, e->w2norm, e->c2b, 64, static_cast<const unsigned*>(nullptr), B,
@@ -3017,7 +3014,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       if (e->train_f16 == 2)
         hipLaunchKernelGGL((conv2_f16x3_kernel<3, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih,
                            reinterpret_cast<const h16x8*>(ws + T.t_pool1_l16), wf2);
-      else hipLaunchKernelGGL((conv2_f16x3_kernel<1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, ih, wf2);
+      else hipLaunchKernelGGL((conv2_f16x3_kernel<1, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, ih, wf2);
       MST_HIP_CHECK(hipGetLastError());
     } else {
       const int g = std::min(grid, ns * cp.sets_per_band);
