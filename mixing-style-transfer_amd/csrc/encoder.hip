@@ -1925,7 +1925,7 @@ struct WgradParams {
   int B, nsub, tiles_r, tiles_c;
   int in_rows, in_cols, in_cstride, in_bandoff;
   long long in_clipstride;
-  int dbg;                 // timing experiments (conv2 kernel): 1 skip MFMAs, 2 skip prefetch, 4 skip the A-operand LDS reads
+  int dbg;                 // unused (was: timing experiments of the conv2 kernel)
 };
 
 // NW waves per workgroup (4: two independent workgroups per CU, so that one's loads / barrier overlap the other's MFMAs)
@@ -2299,12 +2299,9 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
     __builtin_amdgcn_sched_barrier(0);
     const float* pb = patch[buf];
     const float* dyl = dybuf[buf];
-    f32x4 ac[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4)
-        ac[c][t4] = (p.dbg & 4) ? f32x4{1.f, 2.f, 3.f, 4.f} : reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + t4];
+    // A operands (dy, 4 M-tiles x 16 k-steps): read from the LDS copy four k-steps at a time inside each N-tile -- all 64
+    // values resident next to 64 accumulators, the B blocks and two prefetch sets overflowed the register file (93 spills)
+    f32x4 ac[4];
     const bool low = 8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.in_rows;   // at most rows 8tr, 8tr+1 exist   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
     float bq[2][16];
     auto load_b = [&](int k, float (&b)[16]) __attribute__((always_inline)) {
@@ -2321,22 +2318,24 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
+          if ((e & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ac[c] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + (e >> 2)];
+          }
           const float b = bq[k & 1][e];
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c][e >> 2][e & 3], b, acc[c][k], 0, 0, 0);
+            acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c][e & 3], b, acc[c][k], 0, 0, 0);
           if ((e & 3) == 2 && e < 8) {   // two prefetch instructions per N-tile, in the k-steps every tile executes
-            if (!(p.dbg & 2)) prefetch_piece(piece, pfn, dqn, pmn);
+            prefetch_piece(piece, pfn, dqn, pmn);
             ++piece;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     };
-    if (!(p.dbg & 1)) {
-      if (low) mma(std::integral_constant<int, 8>{});
-      else mma(std::integral_constant<int, 16>{});
-    }
+    if (low) mma(std::integral_constant<int, 8>{});
+    else mma(std::integral_constant<int, 16>{});
     {   // shared N-tile 24: two k-steps per wave (one in the low tiles)
       const int e0 = low ? wave : 2 * wave, cnt = low ? 1 : 2;
 #pragma unroll
@@ -3286,7 +3285,7 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   MST_HIP_CHECK(hipMemsetAsync(dwa, 0, (size_t)ndw * sizeof(mst::DetAcc), st));
   WgradParams wp{pool1, reinterpret_cast<const float*>(ws + T.y2), dwa, B, ns, T.tr2, T.tc2,
                  e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1,
-                 getenv("MST_WGRAD_DBG") ? atoi(getenv("MST_WGRAD_DBG")) : 0};
+                 0};
   const long long total = (long long)ns * B * T.tr2 * T.tc2;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv2_wgrad: too many tiles");
   const int g = (int)std::min<long long>(e->num_cus & ~3, 4 * total);   // groups of 4 workgroups (one per input-channel chunk)
