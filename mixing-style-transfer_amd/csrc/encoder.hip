@@ -395,8 +395,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bool low_rows = MODE == 1 && LAYER == 2 && __builtin_amdgcn_readfirstlane(cur.tr) >= 1 &&
-                          8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.raw_rows;   // wave-uniform
     // 49 taps x (MT A-fragments, NT B-fragments, MT*NT MFMAs); the fragments of tap+1 are read from LDS and PPT
     // pieces of the next chunk are fetched from global memory while the MFMAs of this tap are in flight
     {
@@ -414,9 +412,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
         for (int i = 0; i < MT * NT; ++i) {
           const int t = i / NT, n = i % NT;
-          // training forward, second tile row of conv2 (output rows 8..15 of 10): M-tiles 2, 3 are rows 10.. -> skipped
-          if (!(MODE == 1 && LAYER == 2 && t >= 2 && low_rows))
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+          // (no per-MFMA skipping of M-tiles past the plane: a wave-uniform branch here cost the training forward half its
+          // speed; the last rows of a 10-row plane go through the strip kernel, MODE 3, and otherwise padding rows are computed)
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
           if (tap + 1 < 49) {
             if (i < NT) b[nx][i] = wb[((tap + 1) * NT + i) * 64 + lane];   // B first: needed by the next tap's MFMA 0
             else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
@@ -3149,7 +3147,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
     MST_REQUIRE(layer == 2 || dy == nullptr, "mst_encoder_train_backward_apply: f16 training keeps layer 1's dy in the workspace (pass dy = NULL)");
     const int CG = (B + 7) / 8;
     const long long gunits = (long long)ns * CG * wus * 64;
-    const dim3 gg((unsigned)((gunits + 255) / 256));
+    const dim3 gg((unsigned)((2 * gunits + 255) / 256));   // two threads (4 clips each) per lane-unit
     const bool x3 = e->train_f16 == 2;
     if (layer == 1) {
       h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg1);
