@@ -531,7 +531,9 @@ class MixingStyleEncoder(nn.Module):
             raise ValueError("train_precision must be 'fp32', 'f16', 'f16x3' or 'auto'")
         want = self.train_precision
         if want == "auto":
-            want = "f16" if torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.float16 else "fp32"
+            amp16 = torch.is_autocast_enabled() and (torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype")
+                                                     else torch.get_autocast_gpu_dtype()) == torch.float16
+            want = "f16" if amp16 else "fp32"
         if want != "fp32" and enc.sub != 2 and ae.split_size % 2:
             why = f"split_size={ae.split_size}: the f16 training kernels need an even split_size; the trunk stays fp32"
             if self.train_precision != "auto":
