@@ -190,3 +190,40 @@ def test_song_a_real_music_config0():
     sd = cases.make_state_dict(cases.CFG_DEFAULT, seed=42)
     emb = oenc.encoder_from_logmel(sd, lm, torch.from_numpy(g["features"]))
     close(emb.numpy(), g["embedding"], rtol=1e-4, atol=1e-5 * np.abs(g["embedding"]).max())
+
+
+def test_f16_training_oracle_is_pinned_to_torch_autocast():
+    """The f16 training mode's arithmetic contract (oracle/train_f16.py: conv operands rounded to float16, fp32 accumulation, the
+    output stored as float16) is what the reference's `--use_amp` step runs -- `torch.autocast(float16)` around the model
+    (src/train.py:251-253).  PyTorch's own autocast convolution (CPU build, same semantics as the GPU one) pins the restatement:
+    with the bias rounded too, as autocast does, at least 99 % of the outputs are identical float16 values and the rest are the
+    neighbouring float16 (accumulation order); with the bias kept in fp32, as the kernels do -- it cancels in the batch-statistics
+    BatchNorm that follows -- every output is within one rounding of y plus the rounding of the bias.  The input gradient of the oracle equals autograd's through the
+    same rounded operands with the upstream gradient rounded to float16."""
+    import torch.nn.functional as F
+    from oracle.encoder import round_f16_ideal as r
+    from oracle.train_f16 import _F16OperandConv
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 8, 20, 40, generator=g)
+    w = torch.randn(32, 8, 7, 7, generator=g) * 0.05
+    b = torch.randn(32, generator=g) * 0.1
+    with torch.autocast("cpu", dtype=torch.float16):
+        y = F.conv2d(x, w, b, padding=3)
+    assert y.dtype == torch.float16
+    y = y.double()
+    ulp = torch.ldexp(torch.ones_like(y), torch.frexp(y)[1] - 11)           # float16 spacing at |y|
+    ours = _F16OperandConv.apply(x.double(), w.double(), b.double(), (3, 3))
+    assert ((ours - y).abs() <= 2.0 ** -10 * (y.abs() + b.abs().max())).all()   # the roundings of y and of autocast's bias
+    amp_like = r(F.conv2d(r(x).double(), r(w).double(), r(b).double(), padding=3))
+    same = (amp_like == y).double().mean().item()
+    # the rest: a neighbouring float16 where PyTorch's fp32 accumulation order rounds the other way (a few ulps of y where the
+    # products cancel: the error is relative to the partial sums, not to y)
+    assert same >= 0.99 and ((amp_like - y).abs() <= torch.maximum(ulp * 1.0001, torch.full_like(y, 2.0 ** -12))).all(), same
+    # gradients: dx = conv^T(r(dy), r(w)), dW = corr(r(x), r(dy)); the output rounding is transparent (a cast)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    dy = torch.randn(2, 32, 20, 40, generator=g).double() * 1e-3
+    _F16OperandConv.apply(xd, wd, b.double(), (3, 3)).backward(dy)
+    xr, wr = r(x.double()).requires_grad_(True), r(w.double()).requires_grad_(True)
+    F.conv2d(xr, wr, b.double(), padding=3).backward(r(dy))
+    close(xd.grad.numpy(), xr.grad.numpy(), rtol=1e-12, atol=1e-15)
+    close(wd.grad.numpy(), wr.grad.numpy(), rtol=1e-12, atol=1e-15)
