@@ -269,12 +269,18 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
   const int G = gridDim.x;
   const int wg = mst::xcd_remap(blockIdx.x, G);
   const int total_sets = p.nsub * p.sets_per_band;
-  const int my_sets = wg < total_sets ? (total_sets - wg + G - 1) / G : 0;
+  // sets are dealt round-robin over the workgroups, except in the modes that accumulate batch statistics (1, 3): there every
+  // workgroup takes a CONTIGUOUS range, so that its band -- and the flush of the sums, 128..256 integer atomics per wave --
+  // changes once or twice per launch instead of every few tiles (see conv2_f16x3_kernel)
+  constexpr bool CONTIG = MODE == 1 || MODE == 3;
+  const int s_first = CONTIG ? (int)((long long)wg * total_sets / G) : wg;
+  const int my_sets = CONTIG ? (int)((long long)(wg + 1) * total_sets / G) - s_first
+                             : (wg < total_sets ? (total_sets - wg + G - 1) / G : 0);
   const int nq = my_sets * NCH;
   const int tpb = p.tiles_r * p.tiles_c;
 
   auto decode = [&](int q) __attribute__((always_inline)) {
-    const int s = wg + (q / NCH) * G;
+    const int s = CONTIG ? min(s_first + q / NCH, total_sets - 1) : wg + (q / NCH) * G;
     Tile t;
     t.band = min(s / p.sets_per_band, p.nsub - 1);
     const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
@@ -994,6 +1000,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
         const float wi = p.f16_winv[cur.band * C::COUT + n * 16 + j];   // undo the weight pre-scale (exact power of two)
         const size_t unit = unit0 + (size_t)(n * 64 + lane);
         const float sy = MODE == 2 ? p.y_scale[cur.band * 2] : 1.f, isy = MODE == 2 ? p.y_scale[cur.band * 2 + 1] : 1.f;
+        float ps = 0.f, pq = 0.f;   // the tile's 20 values in fp32, then one fold into the double accumulators (see conv2_f16x3_kernel)
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
@@ -1007,11 +1014,12 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
             }
             const int e = 4 * t + r, wv = e / C::WIN, pos = e % C::WIN;
             const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
-            if (col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
+            if (col < p.raw_cols) ps += v[r], pq = fmaf(v[r], v[r], pq);
           }
           if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
           else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
         }
+        st[n][0] += (double)ps, st[n][1] += (double)pq;
       }
     } else {
       const int j = lane & 15, g = lane >> 4;
@@ -1088,11 +1096,16 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
   const int G = gridDim.x;
   const int wg = mst::xcd_remap(blockIdx.x, G);
   const int total_sets = p.nsub * p.sets_per_band;
-  const int my_sets = wg < total_sets ? (total_sets - wg + G - 1) / G : 0;
+  // eval: sets dealt round-robin over the workgroups.  Training (MODE >= 1): every workgroup takes a CONTIGUOUS range of sets, so
+  // that its band -- and with it the flush of the batch-statistics sums, 256 integer atomics per wave -- changes once or twice
+  // per launch instead of every third tile (the round-robin deal spent more time in those atomics than in the MFMAs)
+  const int s_first = MODE >= 1 ? (int)((long long)wg * total_sets / G) : wg;
+  const int my_sets = MODE >= 1 ? (int)((long long)(wg + 1) * total_sets / G) - s_first
+                                : (wg < total_sets ? (total_sets - wg + G - 1) / G : 0);
   const int nq = my_sets * NCH;
   const int tpb = p.tiles_r * p.tiles_c;
   auto decode = [&](int q) __attribute__((always_inline)) {
-    const int s = wg + (q / NCH) * G;
+    const int s = MODE >= 1 ? min(s_first + q / NCH, total_sets - 1) : wg + (q / NCH) * G;
     Tile t;
     t.band = min(s / p.sets_per_band, p.nsub - 1);
     const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
@@ -1247,6 +1260,9 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
         const float wi = inv_s * p.f16_winv[cur.band * 64 + n * 16 + j];   // input range scale and weight pre-scale, exact powers of two
         const size_t unit = unit0 + (size_t)(n * 64 + lane);
         const float sy = MODE == 2 ? p.y_scale[cur.band * 2] : 1.f, isy = MODE == 2 ? p.y_scale[cur.band * 2 + 1] : 1.f;
+        // the tile's 16 values are summed in fp32 first and folded into the double accumulators once per tile: on this
+        // MFMA-light kernel 128 fp64 operations per lane and tile cost more than the convolution (3.07 -> 1.98 ms without them)
+        float ps = 0.f, pq = 0.f;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
@@ -1259,11 +1275,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
               v[r] = (float)h[r] * isy;
             }
             const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
-            if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
+            if (row < p.raw_rows && col < p.raw_cols) ps += v[r], pq = fmaf(v[r], v[r], pq);
           }
           if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
           else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
         }
+        st[n][0] += (double)ps, st[n][1] += (double)pq;
       }
     }
     if (MODE == 0 && chunk == NCH - 1 && cur.valid) {
