@@ -46,3 +46,12 @@ def test_gpus_2_launches_two_ranks_itself():
     out = _bench(["--gpus", "2"] + SMALL, MST_BENCH_ONE_GPU="1", MST_BENCH_BACKEND="gloo")
     assert out["n_gpus"] == 2 and out["world"] == 2 and out["rccl_ranks_seen"] == 2
     assert out["config"]["parallelism"] == "clip-sharded x2" and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "amp"])
+def test_train_step_line_by_precision(precision):
+    """`bench.py --train --train-precision ...` (extra measurement, not the contract line): the hand-written trunk in split
+    precision, and the reference's --use_amp step (autocast + GradScaler around the float16-operand trunk)."""
+    out = _bench(["--train", "--train-precision", precision, "--steps", "2", "--warmup", "1", "--triplets", "3", "--seconds", "2"])
+    assert out["config"]["train_precision"] == precision and out["config"]["train_backend"] == "hip"
+    assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"] and "NOT THE CONTRACT LINE" in out["config"]["workload"]
