@@ -48,6 +48,9 @@ def parse():
                     help="extra measurement, not the contract line: a full TRAINING step (stage A, encoder forward + backward "
                          "with train-mode BatchNorm and Dropout, InfoNCE forward + backward, AdamW) instead of the forward path")
     ap.add_argument("--train-backend", choices=["hip", "torch"], default="hip")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="--train with --gpus N > 1: the ranks add up their BatchNorm statistics (exact integer sums over RCCL), so "
+                         "that the N-GPU step is the single-process step on the whole batch; default: per-rank statistics")
     ap.add_argument("--train-precision", choices=["fp32", "f16", "f16x3", "amp"], default="fp32",
                     help="--train only.  fp32: exact fp32 MFMA trunk.  f16: the hand-written trunk with float16 operands / fp32 "
                          "accumulation (BASELINE configs[4]'s fp16), everything else fp32.  f16x3: the same kernels with 3-term split-precision "
@@ -274,6 +277,7 @@ def main():
         model.train()
         model.train_backend = a.train_backend
         model.train_precision = {"fp32": "fp32", "f16": "f16", "f16x3": "f16x3", "amp": "auto"}[a.train_precision]
+        model.sync_bn = bool(a.sync_bn)
         opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
         crit_t = InfoNCELoss(0.1, gather=world > 1)
         amp = a.train_precision == "amp"
@@ -329,6 +333,7 @@ def main():
                                        "encoder forward + backward (train-mode BatchNorm, Dropout 0.3), InfoNCE forward + backward, "
                                        f"AdamW; {a.triplets} triplets = {B} clips of {a.seconds:.0f} s per GPU",
                            "clips_per_gpu": B, "train_backend": a.train_backend, "train_precision": a.train_precision,
+                           "sync_bn": bool(a.sync_bn),
                            "loss": float(loss.detach()),
                            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}}), flush=True)
         if world > 1:

@@ -164,8 +164,22 @@ typedef struct mst_encoder_train_taps {
   const unsigned char* drop1_mask; /* optional INPUT dev, layout of pool1: Dropout keep-mask after the first pooling
                                       (src/model.py:118: Dropout(0.3)); pool1 = mask ? pooled * drop1_scale : 0 */
   float drop1_scale;               /* 1 / (1 - p) */
+  /* Data-parallel training with CROSS-RANK BatchNorm statistics (what the single-process reference computes on
+   * the whole batch, src/model.py:107-125 under src/train.py:211).  phase 0 (default): the whole forward.  Otherwise the
+   * forward runs in three calls with the same arguments -- 1: FiLM + conv1 raw output and its statistics; 2: BatchNorm 1 +
+   * FiLM + pooling + conv2 raw output and its statistics; 3: BatchNorm 2 + FiLM + pooling + head -- and between the calls
+   * the caller SUMS the statistics accumulators over its ranks (mst_encoder_train_stats_buffer: 64-bit integers, so the sum
+   * is exact and order-independent).  count_scale: ranks that contribute (the accumulators then hold count_scale * B clips);
+   * 0 = 1.                                                                                                              */
+  int phase;
+  double count_scale;
 } mst_encoder_train_taps;
 size_t mst_encoder_train_workspace_bytes(const mst_encoder* enc, int B, int frames);
+/* Where the statistics accumulators of conv layer 1 or 2 sit inside the training workspace: byte offset and number of
+ * int64 words ([n_sub][C][2 sums][2 words]).  The forward (sum y, sum y^2) and the backward pass (sum dz, sum dz * zhat)
+ * use the same words; all-reduce them with SUM between the phases.  Returns 0 on success.                          */
+int mst_encoder_train_stats_buffer(const mst_encoder* enc, int layer, int B, int frames, size_t* offset_bytes,
+                                   size_t* n_int64);
 int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int frames, const float* feats, int B,
                               float* emb, const mst_encoder_train_taps* taps, void* workspace,
                               size_t workspace_bytes, void* stream);
@@ -209,6 +223,17 @@ int mst_encoder_update_trunk_params(mst_encoder* enc, const float* conv1_w, cons
 int mst_encoder_train_backward_apply(const mst_encoder* enc, int layer, int B, int frames, const float* dpool,
                                      long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream);
+/* The same in phases, for cross-rank BatchNorm statistics (see mst_encoder_train_taps::phase): 0 = everything (the call
+ * above); 1 = (f16 training modes, layer 2) max |d pool_in| of this rank into the scale word -- all-reduce it with MAX
+ * (mst_encoder_train_scale_buffer), so that every rank derives the same internal loss scale; 2 = pass A, the sums over this
+ * rank's clips -- all-reduce the layer's statistics buffer with SUM; 3 = pass B and the outputs.  count_scale as above.  */
+int mst_encoder_train_backward_apply_phase(const mst_encoder* enc, int layer, int B, int frames, const float* dpool,
+                                           long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
+                                           float* dbn, void* workspace, size_t workspace_bytes, void* stream, int phase,
+                                           double count_scale);
+/* f16 training modes: byte offset inside the workspace of the 32-bit word that holds max |d pool_in| as a float bit pattern
+ * (non-negative floats order like unsigned integers: all-reduce with MAX on int32).  Returns non-zero in fp32 mode.     */
+int mst_encoder_train_scale_buffer(const mst_encoder* enc, int B, int frames, size_t* offset_bytes);
 
 /* conv1 weight gradient, hand-written fp32-MFMA GEMM over positions.  Call after
  * mst_encoder_train_backward_apply(layer 1) with dy == NULL: that variant leaves d(conv1 output) in the workspace, in

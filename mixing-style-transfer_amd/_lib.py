@@ -41,7 +41,8 @@ class EncoderTaps(C.Structure):
 
 class EncoderTrainTaps(C.Structure):
     _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("bn1", C.c_void_p),
-                ("bn2", C.c_void_p), ("film_in", C.c_void_p), ("drop1_mask", C.c_void_p), ("drop1_scale", C.c_float)]
+                ("bn2", C.c_void_p), ("film_in", C.c_void_p), ("drop1_mask", C.c_void_p), ("drop1_scale", C.c_float),
+                ("phase", C.c_int), ("count_scale", C.c_double)]
 
 
 class AugStem(C.Structure):
@@ -84,6 +85,12 @@ SYMBOLS = {
     "mst_encoder_train_backward_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                                    C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_backward_apply_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
+                                                         C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_double]),
+    "mst_encoder_train_stats_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t),
+                                                 C.POINTER(C.c_size_t)]),
+    "mst_encoder_train_scale_buffer": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
     "mst_encoder_update_trunk_params": (C.c_int, [C.c_void_p] * 10),
     "mst_encoder_train_conv1_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_size_t, C.c_void_p]),

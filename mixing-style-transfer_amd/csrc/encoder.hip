@@ -2868,6 +2868,22 @@ size_t mst_encoder_train_workspace_bytes(const mst_encoder* e, int B, int frames
   return train_layout(e, B, frames).total;
 }
 
+int mst_encoder_train_stats_buffer(const mst_encoder* e, int layer, int B, int frames, size_t* offset_bytes, size_t* n_int64) {
+  MST_REQUIRE(e && offset_bytes && n_int64 && (layer == 1 || layer == 2) && B > 0 && frames >= 20,
+              "mst_encoder_train_stats_buffer: bad arguments");
+  const TrainLayout T = train_layout(e, B, frames);
+  *offset_bytes = layer == 1 ? T.stats1 : T.stats2;
+  *n_int64 = (size_t)e->cfg.n_subbands * (layer == 1 ? 32 : 64) * 2 * (sizeof(mst::DetAcc) / 8);
+  return MST_OK;
+}
+
+int mst_encoder_train_scale_buffer(const mst_encoder* e, int B, int frames, size_t* offset_bytes) {
+  MST_REQUIRE(e && offset_bytes && B > 0 && frames >= 20, "mst_encoder_train_scale_buffer: bad arguments");
+  MST_REQUIRE(train_bwd16(e), "mst_encoder_train_scale_buffer: the fp32 training mode has no internal loss scale");
+  *offset_bytes = train_layout(e, B, frames).t_bscale + 2 * sizeof(float);
+  return MST_OK;
+}
+
 int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
                               const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(e && logmel && (feats || (taps && taps->film_in)), "mst_encoder_forward_train: NULL argument");
@@ -2890,6 +2906,16 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   float* y2 = reinterpret_cast<float*>(ws + T.y2);
   mst::DetAcc* stats1 = reinterpret_cast<mst::DetAcc*>(ws + T.stats1);
   mst::DetAcc* stats2 = reinterpret_cast<mst::DetAcc*>(ws + T.stats2);
+  // phases (taps->phase; 0 = everything): 1 = FiLM + conv1 raw output + its statistics; 2 = BatchNorm 1 + FiLM + pooling + conv2
+  // raw output + its statistics; 3 = BatchNorm 2 + FiLM + pooling + head.  Between the phases a data-parallel caller sums the
+  // statistics accumulators over its ranks (mst_encoder_train_stats_buffer) and passes count_scale = world size.
+  const int phase = taps ? taps->phase : 0;
+  MST_REQUIRE(phase >= 0 && phase <= 3, "mst_encoder_forward_train: phase %d (0..3)", phase);
+  const bool run_a = phase == 0 || phase == 1, run_b = phase == 0 || phase == 2, run_c = phase == 0 || phase == 3;
+  const double cscale = (taps && taps->count_scale > 0.0) ? taps->count_scale : 1.0;
+  const int grid = e->num_cus;
+  hipError_t err;
+  if (run_a) {
   MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * sizeof(mst::DetAcc), st));
   MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * sizeof(mst::DetAcc), st));
   if (taps && taps->film_in) {   // FiLM parameters computed by the caller (its MLP keeps its autograd graph)
@@ -2903,8 +2929,6 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     hipLaunchKernelGGL(film_kernel, dim3(B, groups), dim3(256), lds, st, fp);
     MST_HIP_CHECK(hipGetLastError());
   }
-  const int grid = e->num_cus;
-  hipError_t err;
   {   // conv1 raw + statistics
     ConvParams cp{};
     cp.in = logmel, cp.wfrag = e->w1frag, cp.B = B, cp.nsub = ns;
@@ -2965,8 +2989,12 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       hipLaunchKernelGGL((conv_kernel<1, 1, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
     }
     MST_HIP_CHECK(hipGetLastError());
+  }
+  }   // run_a
+  if (run_b) {
+  {
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn1);
-    FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, (double)B * e->cfg.split_size * frames, e->cfg.bn_eps,
+    FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, cscale * B * e->cfg.split_size * frames, e->cfg.bn_eps,
                   ns, 32, 0, 32};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
@@ -3061,8 +3089,12 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       hipLaunchKernelGGL((conv_kernel<4, 2, 3>), dim3(g), dim3(kConvThreads), lds, st, sp);
       MST_HIP_CHECK(hipGetLastError());
     }
+  }
+  }   // run_b
+  if (run_c) {
+  {
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn2);
-    FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, (double)B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
+    FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, cscale * B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
     ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64,
                    nullptr, nullptr, L.W1};
@@ -3092,13 +3124,25 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   if (taps && taps->film) MST_HIP_CHECK(hipMemcpyAsync(taps->film, film, (size_t)B * ns * 192 * 4, hipMemcpyDeviceToDevice, st));
   if (taps && taps->bn1) MST_HIP_CHECK(hipMemcpyAsync(taps->bn1, ws + T.bn1, (size_t)ns * 32 * 8, hipMemcpyDeviceToDevice, st));
   if (taps && taps->bn2) MST_HIP_CHECK(hipMemcpyAsync(taps->bn2, ws + T.bn2, (size_t)ns * 64 * 8, hipMemcpyDeviceToDevice, st));
+  }   // run_c
   return MST_OK;
 }
 
 int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int frames, const float* dpool,
                                      long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream) {
+  return mst_encoder_train_backward_apply_phase(e, layer, B, frames, dpool, dp_clip, dp_band, dp_ch, dy, dfilm, dbn, workspace,
+                                                workspace_bytes, stream, 0, 1.0);
+}
+
+int mst_encoder_train_backward_apply_phase(const mst_encoder* e, int layer, int B, int frames, const float* dpool,
+                                           long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
+                                           float* dbn, void* workspace, size_t workspace_bytes, void* stream, int phase,
+                                           double count_scale) {
   MST_REQUIRE(e && dpool && dfilm && dbn, "mst_encoder_train_backward_apply: NULL argument");
+  MST_REQUIRE(phase >= 0 && phase <= 3, "mst_encoder_train_backward_apply: phase %d (0..3)", phase);
+  const bool run_1 = phase == 0 || phase == 1, run_2 = phase == 0 || phase == 2, run_3 = phase == 0 || phase == 3;
+  const double cscale = count_scale > 0.0 ? count_scale : 1.0;
 
   MST_REQUIRE((layer == 1 || layer == 2) && B > 0 && frames >= 20, "mst_encoder_train_backward_apply: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
@@ -3115,9 +3159,11 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
   const int cout = layer == 1 ? 32 : 64;
   mst::DetAcc* sums = reinterpret_cast<mst::DetAcc*>(ws + (layer == 1 ? T.stats1 : T.stats2));   // forward sums are spent: reuse
   p.sums = sums;
-  MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * sizeof(mst::DetAcc), st));
   p.dfilm_acc = reinterpret_cast<mst::DetAcc*>(ws + T.dfilm_acc);
-  MST_HIP_CHECK(hipMemsetAsync(p.dfilm_acc, 0, (size_t)B * ns * 192 * sizeof(mst::DetAcc), st));
+  if (run_2) {
+    MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * sizeof(mst::DetAcc), st));
+    MST_HIP_CHECK(hipMemsetAsync(p.dfilm_acc, 0, (size_t)B * ns * 192 * sizeof(mst::DetAcc), st));
+  }
   // f16 training: the backward pass runs under an internal power-of-two loss scale s chosen from max |d pool_in| (layer 2 =
   // the start of the trunk's backward); d pool1 carries it to layer 1; every result that leaves the trunk is divided by s.
   // In this mode `dy` of layer 2 is the f16 channel-minor operand of the f16 dgrad kernel, [n_sub][B][H1][W1][64] halves.
@@ -3129,9 +3175,11 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
       MST_REQUIRE(dp_ch == (long long)e->FD * L.W2 && dp_band == 64 * dp_ch && dp_clip == (long long)ns * dp_band,
                   "mst_encoder_train_backward_apply: f16 training expects a contiguous d pool_in");
       unsigned* bits = reinterpret_cast<unsigned*>(bs + 2);
-      MST_HIP_CHECK(hipMemsetAsync(bits, 0, sizeof(unsigned), st));
-      hipLaunchKernelGGL(absmax_kernel, dim3(256, 1), dim3(256), 0, st, dpool, (long long)B * dp_clip, bits);
-      hipLaunchKernelGGL(f16_bscale_kernel, dim3(1), dim3(1), 0, st, bits, bs);
+      if (run_1) {
+        MST_HIP_CHECK(hipMemsetAsync(bits, 0, sizeof(unsigned), st));
+        hipLaunchKernelGGL(absmax_kernel, dim3(256, 1), dim3(256), 0, st, dpool, (long long)B * dp_clip, bits);
+      }
+      if (run_2) hipLaunchKernelGGL(f16_bscale_kernel, dim3(1), dim3(1), 0, st, bits, bs);
       p.in_scale = bs;
       p.dy_h16 = reinterpret_cast<_Float16*>(dy);
       p.dy = nullptr;
@@ -3145,7 +3193,7 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
     p.pool_h = e->sub;
     if (e->train_f16 == 1) p.y_scale = reinterpret_cast<const float*>(ws + T.t_ys1);
     p.rows = e->cfg.split_size, p.cols = frames, p.goff = 0, p.boff = 32;
-    p.count = (double)B * e->cfg.split_size * frames;
+    p.count = cscale * B * e->cfg.split_size * frames;
   } else {
     p.yraw = reinterpret_cast<const float*>(ws + T.y2), p.aff = reinterpret_cast<const float2*>(ws + L.aff2);
     p.dy_acc = reinterpret_cast<float*>(ws + T.y2);   // layer 2: always kept in accumulator order as well (conv2 wgrad; fp32 mode only)
@@ -3153,46 +3201,53 @@ int mst_encoder_train_backward_apply(const mst_encoder* e, int layer, int B, int
     p.bnstat = reinterpret_cast<const float2*>(ws + T.bn2), p.bn_w = e->bn2w, p.bn_b = e->bn2b;
     p.dp_rows = e->FD, p.dp_cols = L.W2, p.tiles_r = T.tr2, p.tiles_c = T.tc2;
     p.rows = e->H1, p.cols = L.W1, p.goff = 64, p.boff = 128;
-    p.count = (double)B * e->H1 * L.W1;
+    p.count = cscale * B * e->H1 * L.W1;
   }
   const int nt = layer == 1 ? 2 : 4;
   const int wus = p.tiles_r * p.tiles_c * nt;
   p.chunks = std::max(1, std::min(16, wus / 64));
   const long long units = (long long)B * ns * wus * 64;
   const dim3 gr(p.chunks, B * ns), gd((unsigned)((units + 255) / 256));
-  if (train_bwd16(e)) {   // pass A unchanged; pass B writes f16 d(conv output) in the weight gradient's operand layout
-    MST_REQUIRE(layer == 2 || dy == nullptr, "mst_encoder_train_backward_apply: f16 training keeps layer 1's dy in the workspace (pass dy = NULL)");
-    const int CG = (B + 7) / 8;
-    const long long gunits = (long long)ns * CG * wus * 64;
-    const dim3 gg((unsigned)((2 * gunits + 255) / 256));   // two threads (4 clips each) per lane-unit
-    const bool x3 = e->train_f16 == 2;
-    if (layer == 1) {
-      h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg1);
-      hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
-      if (x3) hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2, 3>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
-      else hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2, 1>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
-    } else {
-      h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg2);
-      hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
-      if (x3) hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2, 3>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
-      else hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2, 1>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
-    }
-  } else if (layer == 1 && e->sub == 2) {
-    hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 2>), gd, dim3(256), 0, st, p, units);
-  } else if (layer == 1) {
-    hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 1>), gr, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 1>), gd, dim3(256), 0, st, p, units);
-  } else {
-    hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
-    hipLaunchKernelGGL((apply_bwd_dx_kernel<2, 2>), gd, dim3(256), 0, st, p, units);
+  // pass A (run_2): the sums over this rank's clips, and from them the BatchNorm parameter gradients and the FiLM gradients --
+  // LOCAL contributions: with cross-rank statistics the caller all-reduces the sums AFTER this point, and its ordinary
+  // gradient all-reduce adds up the ranks' dbn.  pass B (run_3): d(conv output) from the (global) sums.
+  if (run_2) {
+    if (layer == 1 && (e->sub == 2 || train_bwd16(e))) hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 2>), gr, dim3(256), 0, st, p);
+    else if (layer == 1) hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 1>), gr, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
+    MST_HIP_CHECK(hipGetLastError());
+    // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
+    hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout, unscale);
+    hipLaunchKernelGGL(dfilm_finish_kernel, dim3((B * ns * 2 * cout + 255) / 256), dim3(256), 0, st, p.dfilm_acc, dfilm,
+                       B * ns * 192, p.goff, p.boff, cout, unscale);
+    MST_HIP_CHECK(hipGetLastError());
   }
-  MST_HIP_CHECK(hipGetLastError());
-  // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
-  hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout, unscale);
-  hipLaunchKernelGGL(dfilm_finish_kernel, dim3((B * ns * 2 * cout + 255) / 256), dim3(256), 0, st, p.dfilm_acc, dfilm,
-                     B * ns * 192, p.goff, p.boff, cout, unscale);
-  MST_HIP_CHECK(hipGetLastError());
+  if (run_3) {
+    if (train_bwd16(e)) {   // f16 d(conv output) in the weight gradient's operand layout
+      MST_REQUIRE(layer == 2 || dy == nullptr, "mst_encoder_train_backward_apply: f16 training keeps layer 1's dy in the workspace (pass dy = NULL)");
+      const int CG = (B + 7) / 8;
+      const long long gunits = (long long)ns * CG * wus * 64;
+      const dim3 gg((unsigned)((2 * gunits + 255) / 256));   // two threads (4 clips each) per lane-unit
+      const bool x3 = e->train_f16 == 2;
+      if (layer == 1) {
+        h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg1);
+        if (x3) hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2, 3>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
+        else hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<1, 2, 1>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
+      } else {
+        h16x8* dyg = reinterpret_cast<h16x8*>(ws + T.t_dyg2);
+        if (x3) hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2, 3>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
+        else hipLaunchKernelGGL((apply_bwd_dx_f16_kernel<2, 2, 1>), gg, dim3(256), 0, st, p, gunits, dyg, CG);
+      }
+    } else if (layer == 1 && e->sub == 2) {
+      hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 2>), gd, dim3(256), 0, st, p, units);
+    } else if (layer == 1) {
+      hipLaunchKernelGGL((apply_bwd_dx_kernel<1, 1>), gd, dim3(256), 0, st, p, units);
+    } else {
+      hipLaunchKernelGGL((apply_bwd_dx_kernel<2, 2>), gd, dim3(256), 0, st, p, units);
+    }
+    MST_HIP_CHECK(hipGetLastError());
+  }
+  (void)run_1;
   return MST_OK;
 }
 

@@ -226,8 +226,40 @@ class HipEncoder:
             except Exception:
                 pass
 
-    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0):
-        """Train-mode forward in libmst.so (`mst_encoder_forward_train`): BatchNorm with batch statistics.
+    def _ws_view(self, offset, nbytes, dtype):
+        return self._ws_train[offset:offset + nbytes].view(dtype)
+
+    def stats_view(self, layer, B, frames):
+        """int64 view of the statistics accumulators of conv layer 1 / 2 inside the training workspace (forward: sum y, sum y^2;
+        backward: sum dz, sum dz * zhat) -- what data-parallel ranks add up for cross-rank BatchNorm statistics."""
+        off, n = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.lib().mst_encoder_train_stats_buffer(self._h, layer, B, frames, C.byref(off), C.byref(n)),
+                   "mst_encoder_train_stats_buffer")
+        return self._ws_view(off.value, 8 * n.value, torch.int64)
+
+    def scale_view(self, B, frames):
+        """int32 view of the word that holds max |d pool_in| (float bits, non-negative) in the f16 training modes."""
+        off = C.c_size_t()
+        _lib.check(_lib.lib().mst_encoder_train_scale_buffer(self._h, B, frames, C.byref(off)), "mst_encoder_train_scale_buffer")
+        return self._ws_view(off.value, 4, torch.int32)
+
+    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, sync=None):
+        """`forward_train_steps` run to completion; `sync` (an object with `.world`, `.sum(int64 tensor)`, `.max(int32 tensor)`,
+        e.g. DistSync) adds the ranks' BatchNorm statistics between the phases; None = this process only."""
+        steps = self.forward_train_steps(logmel, feats, film, head, drop1_mask, drop1_p, sync.world if sync is not None else 0)
+        try:
+            while True:
+                kind, view = next(steps)
+                getattr(sync, kind)(view)
+        except StopIteration as done:
+            return done.value
+
+    def forward_train_steps(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, world=0):
+        """Generator form of the train-mode forward.  world = 0: one call of `mst_encoder_forward_train`, nothing is yielded.
+        world >= 1: the three phases of include/mst.h; after phase 1 and 2 it yields ("sum", int64 view of that layer's
+        statistics accumulators), which the caller must all-reduce (SUM) over its `world` ranks before resuming.
+        Returns (via StopIteration.value) what `forward_train` returns.
+        Train-mode forward in libmst.so (`mst_encoder_forward_train`): BatchNorm with batch statistics.
         feats (B, Fd): FiLM MLP in HIP; or film (B, n_sub*192): FiLM parameters from the caller's own MLP.
         head=False stops at pool_in (emb is None).  drop1_mask: uint8 keep-mask shaped like pool1 (Dropout after the
         first pooling).  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
@@ -253,13 +285,17 @@ class HipEncoder:
         mask_c = drop1_mask.contiguous() if drop1_mask is not None else None
         if mask_c is not None:
             assert mask_c.dtype == torch.uint8 and tuple(mask_c.shape) == tuple(out["pool1"].shape)
-        t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")],
-                                  _lib.dptr(film_c), _lib.dptr(mask_c), 1.0 / (1.0 - drop1_p) if mask_c is not None else 1.0)
         lm = logmel.contiguous().float()
-        with torch.cuda.device(dev):
-            _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(lm), Fr, _lib.dptr(feats_c), B, _lib.dptr(emb),
-                                                   C.byref(t), _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
-                       "mst_encoder_forward_train")
+        for phase in ((0,) if world == 0 else (1, 2, 3)):
+            t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")],
+                                      _lib.dptr(film_c), _lib.dptr(mask_c), 1.0 / (1.0 - drop1_p) if mask_c is not None else 1.0,
+                                      phase, float(max(world, 1)))
+            with torch.cuda.device(dev):
+                _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(lm), Fr, _lib.dptr(feats_c), B, _lib.dptr(emb),
+                                                       C.byref(t), _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+                           "mst_encoder_forward_train")
+            if phase in (1, 2):
+                yield "sum", self.stats_view(phase, B, Fr)
         return emb, out
 
     TRAIN_MODES = {"fp32": 0, "f16": 1, "f16x3": 2}
@@ -321,8 +357,22 @@ class HipEncoder:
                        "mst_encoder_train_conv2_wgrad")
         return dw
 
-    def backward_apply(self, layer, dpool, dfilm, B, frames, inplace=False):
-        """Backward of pool/ReLU/FiLM/BatchNorm(train) of conv layer 1 or 2 from the activations the last
+    def backward_apply(self, layer, dpool, dfilm, B, frames, inplace=False, sync=None):
+        """`backward_apply_steps` run to completion (see `forward_train` for `sync`)."""
+        steps = self.backward_apply_steps(layer, dpool, dfilm, B, frames, inplace, sync.world if sync is not None else 0)
+        try:
+            while True:
+                kind, view = next(steps)
+                getattr(sync, kind)(view)
+        except StopIteration as done:
+            return done.value
+
+    def backward_apply_steps(self, layer, dpool, dfilm, B, frames, inplace=False, world=0):
+        """Generator form: world = 0 -> one call, nothing yielded; world >= 1 -> phases 1..3 of
+        `mst_encoder_train_backward_apply_phase`, yielding ("max", int32 view) after phase 1 (f16 training modes, layer 2: the
+        ranks must agree on the internal loss scale) and ("sum", int64 view of the layer's sums) after phase 2.
+        The returned dbn are THIS rank's contributions (the trainer's gradient all-reduce adds the ranks up).
+        Backward of pool/ReLU/FiLM/BatchNorm(train) of conv layer 1 or 2 from the activations the last
         `forward_train` call left in its workspace (`mst_encoder_train_backward_apply`).
         dpool: layer 1 (B, n_sub, 32, 10, W1) or any tensor with those dims and arbitrary clip / band / channel
         strides; layer 2 (B, 64*n_sub*freq_dim, W2) = d pool_in.  dfilm (B, n_sub*192) is accumulated in place.
@@ -346,11 +396,17 @@ class HipEncoder:
                 dy = torch.empty(self.n_sub, B, 64, self.split // self.sub, W1, device=dev)
             dbn = torch.empty(self.n_sub, 64, 2, device=dev)
         need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
-        with torch.cuda.device(dev):
-            _lib.check(L.mst_encoder_train_backward_apply(self._h, layer, B, frames, _lib.dptr(dpool), st[0], st[1], st[2],
-                                                          _lib.dptr(dy), _lib.dptr(dfilm), _lib.dptr(dbn),
-                                                          _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
-                       "mst_encoder_train_backward_apply")
+        for phase in ((0,) if world == 0 else (1, 2, 3)):
+            with torch.cuda.device(dev):
+                _lib.check(L.mst_encoder_train_backward_apply_phase(self._h, layer, B, frames, _lib.dptr(dpool), st[0], st[1], st[2],
+                                                                    _lib.dptr(dy), _lib.dptr(dfilm), _lib.dptr(dbn),
+                                                                    _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev), phase,
+                                                                    float(max(world, 1))),
+                           "mst_encoder_train_backward_apply")
+            if phase == 1 and layer == 2 and self.train_f16:
+                yield "max", self.scale_view(B, frames)
+            elif phase == 2:
+                yield "sum", self.stats_view(layer, B, frames)
         return dy, dbn
 
     def forward(self, logmel, feats, taps=False, events=None):
@@ -383,6 +439,21 @@ class HipEncoder:
         return (emb, out) if taps else emb
 
 
+class DistSync:
+    """Cross-rank sums for BatchNorm statistics over a torch.distributed group (RCCL): exact, order-independent integer adds of
+    the kernels' accumulators.  Any object with `.world`, `.sum(int64 tensor)` and `.max(int32 tensor)` will do."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist, self.group, self.world = dist, group, dist.get_world_size(group)
+
+    def sum(self, t):
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+
+    def max(self, t):
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX, group=self.group)
+
+
 _TRAIN_TIMING = bool(os.environ.get("MST_TRAIN_TIMING"))
 _POISON_WS = bool(os.environ.get("MST_POISON_WS"))
 _CONV1_WGRAD_MIOPEN = os.environ.get("MST_CONV1_WGRAD", "") == "miopen"
@@ -400,16 +471,16 @@ class _HipTrunk(torch.autograd.Function):
     last_timing = None
 
     @staticmethod
-    def forward(ctx, enc, logmel, film, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b, drop_p):
+    def forward(ctx, enc, logmel, film, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b, drop_p, sync=None):
         B, _, M, Fr = logmel.shape
         enc.update_trunk_params(c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)
         W1 = Fr // 5
         mask = None
         if drop_p > 0.0:
             mask = (torch.rand(B, enc.n_sub, 32, enc.split // enc.sub, W1, device=logmel.device) >= drop_p).to(torch.uint8)
-        _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p)
+        _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p, sync=sync)
         enc._train_gen = getattr(enc, "_train_gen", 0) + 1   # the saved activations live in the encoder's workspace
-        ctx.enc, ctx.drop_p, ctx.dims, ctx.gen = enc, drop_p, (B, Fr), enc._train_gen
+        ctx.enc, ctx.drop_p, ctx.dims, ctx.gen, ctx.sync = enc, drop_p, (B, Fr), enc._train_gen, sync
         ctx.save_for_backward(logmel, t["pool1"], c1w, c2w, mask)
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
         return t["pool_in"], t["bn1"], t["bn2"]
@@ -434,7 +505,8 @@ class _HipTrunk(torch.autograd.Function):
                 marks.append((name, e))
         mark("start")
         dfilm = torch.zeros(B, ns * 192, device=logmel.device)
-        dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr)
+        sync = ctx.sync
+        dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr, sync=sync)
         mark("apply_bwd2")
         gi, gw2, gb2 = [], [], []
         native_w2, native_d2 = not _CONV2_WGRAD_MIOPEN, not _CONV2_DGRAD_MIOPEN
@@ -461,7 +533,7 @@ class _HipTrunk(torch.autograd.Function):
                 dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
             mark("stack+mask")
         if _CONV1_WGRAD_MIOPEN and not getattr(enc, "train_f16", False):   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (A/B checks)
-            dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr)
+            dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, sync=sync)
             mark("apply_bwd1")
             gw1, gb1 = [], []
             for i in range(ns):
@@ -470,7 +542,7 @@ class _HipTrunk(torch.autograd.Function):
                 gw1.append(b), gb1.append(c)
             gw1, gb1 = torch.stack(gw1), torch.stack(gb1)
         else:                     # hand-written fp32-MFMA weight gradient on dy in accumulator order
-            _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True)
+            _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
             mark("apply_bwd1")
             gw1 = enc.conv1_wgrad(logmel, B, Fr)
             gb1 = torch.zeros(ns, 32, device=logmel.device)   # exactly 0 in front of a batch-statistics BatchNorm
@@ -479,7 +551,7 @@ class _HipTrunk(torch.autograd.Function):
             torch.cuda.synchronize()
             _HipTrunk.last_timing = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
         return (None, None, dfilm, gw1, gb1, dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(),
-                gw2, gb2, dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous(), None)
+                gw2, gb2, dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous(), None, None)
 
 
 class MixingStyleEncoder(nn.Module):
@@ -506,6 +578,11 @@ class MixingStyleEncoder(nn.Module):
         # kernels with 3-term split-precision operands: fp32-equivalent), or "auto" = f16 inside `torch.autocast(dtype=float16)`
         # (what src/train.py:251 turns on), fp32 otherwise
         self.train_precision = "auto"
+        # data-parallel training: False = every rank normalises with the batch statistics of ITS clips (what
+        # DistributedDataParallel without SyncBatchNorm does); True = the ranks of the default torch.distributed group add up
+        # their statistics (exact integer sums over RCCL, 4 small all-reduces per step) and an N-rank step computes what the
+        # single-process reference computes on the whole batch; a DistSync-like object = that, over its group
+        self.sync_bn = False
         self._warned = set()
 
     def _params_version(self):
@@ -547,12 +624,19 @@ class MixingStyleEncoder(nn.Module):
         st = lambda f: torch.stack([f(c) for c in cn])  # noqa: E731
         flat = fe.film_head(fe.feature_mlp(mixing_features))
         p = cn[0].dropout1.p if self.training else 0.0
+        sync = None
+        if self.sync_bn is True:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                sync = DistSync()
+        elif self.sync_bn:
+            sync = self.sync_bn
         pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, st(lambda c: c.conv1.weight), st(lambda c: c.conv1.bias),
                                             st(lambda c: c.bn1.weight), st(lambda c: c.bn1.bias),
                                             st(lambda c: c.conv2.weight), st(lambda c: c.conv2.bias),
-                                            st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias), float(p))
+                                            st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias), float(p), sync)
         with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
-            B, Fr = logmel.shape[0], logmel.shape[-1]
+            B, Fr = logmel.shape[0] * (sync.world if sync is not None else 1), logmel.shape[-1]
             for stat, name, n in ((bn1, "bn1", B * ae.split_size * Fr), (bn2, "bn2", B * (ae.split_size // enc.sub) * (Fr // 5))):
                 mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * (n / max(n - 1, 1))
                 bns = [getattr(c, name) for c in cn]
@@ -597,6 +681,11 @@ class MixingStyleEncoder(nn.Module):
             if why not in self._warned:
                 self._warned.add(why)
                 warnings.warn(msg, RuntimeWarning, stacklevel=2)
+        if auto and self.training and self.sync_bn and "sync_bn" not in self._warned:
+            self._warned.add("sync_bn")
+            warnings.warn("MixingStyleEncoder.sync_bn is implemented by the hand-written HIP trunk only; this call runs the conv "
+                          "stack on PyTorch-ROCm autograd with per-rank BatchNorm statistics (convert the modules with "
+                          "torch.nn.SyncBatchNorm.convert_sync_batchnorm for the same semantics there)", RuntimeWarning, stacklevel=2)
         if self.encoder_backend == "hip" and not auto:
             if self.training:
                 raise RuntimeError("HIP encoder forward implements eval-mode BatchNorm/Dropout; call model.eval() "

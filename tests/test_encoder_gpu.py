@@ -487,6 +487,81 @@ def test_split_precision_training_on_odd_shapes(B, T, n_mels, split, overlap):
     assert np.median(e) < 1e-5 and e.max() < 1e-2, max(errs)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16"])
+def test_cross_rank_batchnorm_statistics_two_shards(precision):
+    """SURVEY C3 / DESIGN section 6: with `sync_bn` an N-rank training step computes what the single-process reference computes on
+    the whole batch.  Two "ranks" are two encoders of this process with 3 clips each, driven in lockstep through the phases of
+    `forward_train_steps` / `backward_apply_steps`; the test plays the all-reduce (integer SUM of the statistics words, MAX of
+    the f16 modes' scale word).  Against one encoder on all 6 clips: pool_in of both shards (forward), d pool1, the FiLM
+    gradients, and -- summed over the shards, as the trainer's gradient all-reduce does -- the BatchNorm and convolution
+    weight gradients.  fp32-grade precisions: 2e-5; float16 operands: the shards' per-rank range scales differ from the
+    single-process ones only by powers of two, results within 1e-3."""
+    from mst_amd.model import HipEncoder
+    cfg = cases.CFG_DEFAULT
+    model, _ = build_model(cfg)
+    B, T, h = 6, 44100, 3
+    x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.1 * c) for c in range(B)], 0).cuda()
+    g = torch.Generator().manual_seed(41)
+    feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
+    Fr = lm.shape[-1]
+    encs = [HipEncoder(model, "fp32") for _ in range(3)]   # [0]: all clips; [1], [2]: the shards
+    params = _stacked_trunk_params(model)
+    for e in encs:
+        e.set_train_precision(precision)
+        e.update_trunk_params(*params)
+
+    def lockstep(gens):   # run generators side by side; after every yield combine the yielded views as the collective would
+        outs = [None] * len(gens)
+        while any(o is None for o in outs):
+            ys = []
+            for i, gen in enumerate(gens):
+                try:
+                    ys.append(next(gen))
+                except StopIteration as done:
+                    outs[i] = done.value
+            if ys:
+                assert len(ys) == len(gens) and len({k for k, _ in ys}) == 1
+                views = [v for _, v in ys]
+                tot = torch.stack(views).sum(0) if ys[0][0] == "sum" else torch.stack(views).max(0).values
+                for v in views:
+                    v.copy_(tot)
+        return outs
+
+    sl = [slice(0, B), slice(0, h), slice(h, B)]
+    (_, t0), = lockstep([encs[0].forward_train_steps(lm, feats, head=False, world=0)])
+    ts = lockstep([encs[i].forward_train_steps(lm[sl[i]].contiguous(), feats[sl[i]].contiguous(), head=False, world=2) for i in (1, 2)])
+    tol = 2e-5 if precision != "f16" else 1e-3
+    pin = torch.cat([ts[0][1]["pool_in"], ts[1][1]["pool_in"]], 0)
+    close(pin.cpu(), t0["pool_in"].cpu(), tol)
+    close(ts[0][1]["bn2"].cpu(), t0["bn2"].cpu(), tol)          # the shards normalise with the GLOBAL statistics
+    # backward from a common d pool_in
+    R = torch.randn(t0["pool_in"].shape, generator=g).cuda()
+    dfilm = [torch.zeros(b, encs[0].n_sub * 192, device="cuda") for b in (B, h, B - h)]
+    (dy2_0, dbn2_0), = lockstep([encs[0].backward_apply_steps(2, R, dfilm[0], B, Fr, world=0)])
+    r2 = lockstep([encs[i].backward_apply_steps(2, R[sl[i]].contiguous(), dfilm[i], sl[i].stop - sl[i].start, Fr, world=2) for i in (1, 2)])
+    dp1_0 = encs[0].conv2_dgrad(dy2_0, B, Fr)
+    dp1 = [encs[i].conv2_dgrad(r2[i - 1][0], sl[i].stop - sl[i].start, Fr) for i in (1, 2)]
+    if precision == "fp32":
+        close(torch.cat(dp1, 0).cpu(), dp1_0.cpu(), tol)
+    gw2_0 = encs[0].conv2_wgrad(t0["pool1"], B, Fr)
+    gw2 = sum(encs[i].conv2_wgrad(ts[i - 1][1]["pool1"], sl[i].stop - sl[i].start, Fr) for i in (1, 2))
+    (_, dbn1_0), = lockstep([encs[0].backward_apply_steps(1, dp1_0, dfilm[0], B, Fr, inplace=True, world=0)])
+    r1 = lockstep([encs[i].backward_apply_steps(1, dp1[i - 1], dfilm[i], sl[i].stop - sl[i].start, Fr, inplace=True, world=2) for i in (1, 2)])
+    gw1_0 = encs[0].conv1_wgrad(lm, B, Fr)
+    gw1 = sum(encs[i].conv1_wgrad(lm[sl[i]].contiguous(), sl[i].stop - sl[i].start, Fr) for i in (1, 2))
+    gtol = 1e-4 if precision != "f16" else 2e-2   # f16: a different scale exponent moves single float16 roundings
+    close(torch.cat(dfilm[1:], 0).cpu(), dfilm[0].cpu(), gtol)
+    close((r2[0][1] + r2[1][1]).cpu(), dbn2_0.cpu(), gtol)
+    close((r1[0][1] + r1[1][1]).cpu(), dbn1_0.cpu(), gtol)
+    close(gw2.cpu(), gw2_0.cpu(), gtol)
+    close(gw1.cpu(), gw1_0.cpu(), gtol)
+    # and without the exchange the shards do NOT reproduce the whole batch (per-rank statistics, the default)
+    (_, tl), = lockstep([encs[1].forward_train_steps(lm[sl[1]].contiguous(), feats[sl[1]].contiguous(), head=False, world=0)])
+    assert (tl["pool_in"] - t0["pool_in"][sl[1]]).abs().max().item() > 1e-3 * t0["pool_in"].abs().max().item()
+
+
 def _stacked_trunk_params(model):
     cn = model.audio_encoder.subnet_cnns
     st = lambda f: torch.stack([f(c) for c in cn]).detach()  # noqa: E731

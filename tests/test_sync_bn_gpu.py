@@ -1,0 +1,75 @@
+"""GPU: cross-rank BatchNorm statistics (`MixingStyleEncoder.sync_bn`) over a real torch.distributed group.
+Two ranks on the box's single GPU (gloo carries the CUDA tensors here -- RCCL refuses two ranks on one device; the calls are
+the ones RCCL serves on a node: all_reduce SUM on int64, MAX on int32): the summed parameter gradients of the two-rank step
+equal the single-process step on the whole batch, which is what the reference trains (src/train.py:211 on one GPU)."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, precision, ret):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    import cases
+    from oracle import mel as omel
+    from test_encoder_gpu import build_model
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        cfg = cases.CFG_DEFAULT
+        model, _ = build_model(cfg)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        whole = copy.deepcopy(model)
+        model.train(), whole.train()
+        model.train_backend = whole.train_backend = "hip-strict"
+        model.train_precision = whole.train_precision = precision
+        model.sync_bn = True
+        B, T, h = 6, 44100, 3
+        x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.1 * c) for c in range(B)], 0).cuda()
+        g = torch.Generator().manual_seed(43)
+        feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
+        R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
+        with torch.no_grad():
+            lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
+        sl = slice(rank * h, (rank + 1) * h)
+        loss = (model.forward_from_logmel(lm[sl].contiguous(), feats[sl]) * R[sl]).sum()
+        loss.backward()
+        tot = loss.detach().clone()
+        dist.all_reduce(tot)
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        for n in grads:
+            dist.all_reduce(grads[n])                      # the trainer's gradient all-reduce (C2)
+        if rank == 0:
+            lw = (whole.forward_from_logmel(lm, feats) * R).sum()
+            lw.backward()
+            worst = (0.0, "")
+            for n, p in whole.named_parameters():
+                den = p.grad.abs().max().item()
+                if den > 1e-9 and not n.endswith(("conv1.bias", "conv2.bias", "attention.2.bias")):
+                    worst = max(worst, ((grads[n] - p.grad).abs().max().item() / den, n))
+            stat = max((a - b).abs().max().item() for (_, a), (_, b) in zip(model.named_buffers(), whole.named_buffers())
+                       if a.dtype.is_floating_point)
+            ret["loss"] = abs(tot.item() - lw.item()) / abs(lw.item())
+            ret["worst"], ret["stat"] = worst, stat
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
+def test_two_rank_step_with_sync_bn_equals_the_single_process_step(precision):
+    port = 32500 + (os.getpid() % 2000) + (7 if precision == "f16" else 0)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, precision, ret), nprocs=2, join=True)
+    tol = 1e-4 if precision == "fp32" else 3e-2   # f16: per-rank range scales move single float16 roundings
+    print(f"sync_bn, 2 ranks, {precision}: loss {ret['loss']:.2e}, worst gradient {ret['worst']}, running statistics {ret['stat']:.2e}")
+    assert ret["loss"] < (1e-5 if precision == "fp32" else 1e-3) and ret["worst"][0] < tol and ret["stat"] < 1e-4, dict(ret)
