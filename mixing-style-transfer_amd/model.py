@@ -473,27 +473,39 @@ class _HipTrunk(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, logmel, film, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b, drop_p, sync=None):
         B, _, M, Fr = logmel.shape
-        enc.update_trunk_params(c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)
+        trunk = (c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)
+        enc.update_trunk_params(*trunk)
+        enc._frag_gen = getattr(enc, "_frag_gen", 0) + 1   # which forward's parameters the encoder's weight fragments hold
         W1 = Fr // 5
         mask = None
         if drop_p > 0.0:
             mask = (torch.rand(B, enc.n_sub, 32, enc.split // enc.sub, W1, device=logmel.device) >= drop_p).to(torch.uint8)
+        # every forward pass gets its OWN activation workspace (the caching allocator hands the previous step's block back, so a
+        # plain training loop allocates nothing): several forward passes may be alive at once -- retained graphs, two
+        # forwards before one backward -- each backward finds its activations in the workspace its context holds
+        enc._ws_train = None
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p, sync=sync)
-        enc._train_gen = getattr(enc, "_train_gen", 0) + 1   # the saved activations live in the encoder's workspace
-        ctx.enc, ctx.drop_p, ctx.dims, ctx.gen, ctx.sync = enc, drop_p, (B, Fr), enc._train_gen, sync
-        ctx.save_for_backward(logmel, t["pool1"], c1w, c2w, mask)
+        ctx.enc, ctx.drop_p, ctx.dims, ctx.sync = enc, drop_p, (B, Fr), sync
+        ctx.ws, ctx.gen, ctx.mode = enc._ws_train, enc._frag_gen, enc.train_mode
+        ctx.save_for_backward(logmel, t["pool1"], mask, *trunk)
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
         return t["pool_in"], t["bn1"], t["bn2"]
 
     @staticmethod
     def backward(ctx, dpool_in, _d1, _d2):
         enc, (B, Fr) = ctx.enc, ctx.dims
-        if ctx.gen != enc._train_gen:
-            raise RuntimeError("HIP training trunk: backward() of an older forward pass -- the saved activations live in one "
-                               "workspace per model, so every forward must be followed by its backward before the next "
-                               "forward (gradient accumulation over micro-batches is fine); use train_backend='torch' "
-                               "for graphs that keep several forward passes alive")
-        logmel, p1, c1w, c2w, mask = ctx.saved_tensors
+        logmel, p1, mask, *trunk = ctx.saved_tensors
+        c1w, c2w = trunk[0], trunk[4]
+        if getattr(ctx, "consumed", False):
+            raise RuntimeError("HIP training trunk (fp32 mode): second backward() through the same forward pass -- the fp32 kernels "
+                               "turn the saved convolution outputs into their gradients IN PLACE; run the forward again, or use "
+                               "train_precision='f16x3' / 'f16' (their backward leaves the activations intact)")
+        ctx.consumed = ctx.mode == 0
+        enc._ws_train = ctx.ws                       # this pass's activations
+        if ctx.gen != enc._frag_gen or ctx.mode != enc.train_mode:   # another forward re-swizzled the weight fragments since:
+            enc.set_train_precision({v: k for k, v in enc.TRAIN_MODES.items()}[ctx.mode])   # put this pass's parameters back
+            enc.update_trunk_params(*trunk)
+            enc._frag_gen = ctx.gen
         ns, ov, sp = enc.n_sub, enc.overlap, enc.split
         bw = torch.ops.aten.convolution_backward
         marks = []

@@ -816,12 +816,29 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgnam
     for (n, ba), (_, bc) in zip(model.named_buffers(), ref64.named_buffers()):
         if "running" in n:
             close(ba.cpu(), bc.cpu(), 1e-4)
-    # two forward passes alive at once are refused loudly (one activation workspace per model)
-    o1 = model(stems, feats).sum()
-    o2 = model(stems, feats).sum()
-    o2.backward()
-    with pytest.raises(RuntimeError, match="older forward"):
-        o1.backward()
+    # several forward passes may be alive at once (every pass owns its activation workspace): two forwards, then both backwards
+    # in the "wrong" order, give twice the gradient of one pass; walking ONE graph twice works where the backward leaves the
+    # activations intact (the f16 kernels) and is refused loudly where it does not (the fp32 kernels work in place)
+    for prec, walks in (("fp32", 1), ("f16x3", 2)):
+        model.train_precision = prec
+        model.zero_grad()
+        (model(stems, feats) * R).sum().backward()
+        g1 = {n: p.grad.clone() for n, p in model.named_parameters()}
+        model.zero_grad()
+        o1 = (model(stems, feats) * R).sum()
+        o2 = (model(stems, feats) * R).sum()
+        o1.backward(retain_graph=True)
+        o2.backward()
+        if walks == 2:
+            o1.backward()
+        for n, p in model.named_parameters():
+            den = g1[n].abs().max().item()
+            if den > 1e-9:
+                assert (p.grad - (1.0 + walks) * g1[n]).abs().max().item() <= 1e-5 * den * (1.0 + walks), (prec, n)
+        if walks == 1:
+            with pytest.raises(RuntimeError, match="second backward"):
+                o1.backward()
+    model.train_precision = "fp32"
     # dropout after the first pooling: every element is either dropped or scaled by 1 / (1 - p)
     enc = model._hip_train
     with torch.no_grad():
