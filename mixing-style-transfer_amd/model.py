@@ -486,22 +486,23 @@ class _HipTrunk(torch.autograd.Function):
         enc._ws_train = None
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p, sync=sync)
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync = enc, drop_p, (B, Fr), sync
-        ctx.ws, ctx.gen, ctx.mode = enc._ws_train, enc._frag_gen, enc.train_mode
-        ctx.save_for_backward(logmel, t["pool1"], mask, *trunk)
+        ctx.gen, ctx.mode = enc._frag_gen, enc.train_mode
+        # (the workspace rides with the saved tensors: autograd releases it with them after a backward that does not retain the graph)
+        ctx.save_for_backward(logmel, t["pool1"], mask, enc._ws_train, *trunk)
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
         return t["pool_in"], t["bn1"], t["bn2"]
 
     @staticmethod
     def backward(ctx, dpool_in, _d1, _d2):
         enc, (B, Fr) = ctx.enc, ctx.dims
-        logmel, p1, mask, *trunk = ctx.saved_tensors
+        logmel, p1, mask, ws, *trunk = ctx.saved_tensors
         c1w, c2w = trunk[0], trunk[4]
         if getattr(ctx, "consumed", False):
             raise RuntimeError("HIP training trunk (fp32 mode): second backward() through the same forward pass -- the fp32 kernels "
                                "turn the saved convolution outputs into their gradients IN PLACE; run the forward again, or use "
                                "train_precision='f16x3' / 'f16' (their backward leaves the activations intact)")
         ctx.consumed = ctx.mode == 0
-        enc._ws_train = ctx.ws                       # this pass's activations
+        enc._ws_train = ws                           # this pass's activations
         if ctx.gen != enc._frag_gen or ctx.mode != enc.train_mode:   # another forward re-swizzled the weight fragments since:
             enc.set_train_precision({v: k for k, v in enc.TRAIN_MODES.items()}[ctx.mode])   # put this pass's parameters back
             enc.update_trunk_params(*trunk)
