@@ -57,6 +57,10 @@ def parse():
                          "operands (fp32-equivalent results).  amp: the reference's --use_amp step "
                          "(src/train.py:246-262): forward and loss under torch.autocast(float16), GradScaler; the trunk "
                          "switches to its f16 kernels by itself, the torch backend runs MIOpen's half convolutions")
+    ap.add_argument("--logmel-layout", choices=["auto", "ref"], default="auto",
+                    help="auto (default): stage A hands the log-mel to the HIP encoder in its internal channel-minor layout "
+                         "(include/mst.h MST_LOGMEL_CM32; CM16 = float16 hi/lo planes for the f16 / split-precision modes) -- same "
+                         "values, same bytes, whole-line stores; ref: the reference's (B, 8, n_mels, frames) tensor (A/B)")
     ap.add_argument("--ingest", choices=["resident", "f32", "pcm16"], default="resident",
                     help="resident (default, the contract: inputs in HBM before timing) | f32 | pcm16: every step's batch "
                          "comes from pinned host memory over PCIe (double-buffered, overlapped); PCIe-inclusive rate")
@@ -235,6 +239,14 @@ def main():
         e.record()   # materialise the hipEvent_t so the raw handle can be passed through the C ABI
         return e
 
+    from mst_amd import _lib as mlib
+
+    def layout_now():   # the layout the encoder's CURRENT precision mode reads fastest, if stage A can write it
+        if backend != "hip" or a.logmel_layout == "ref":
+            return mlib.LOGMEL_REF
+        lay = model.hip_encoder().preferred_layout()
+        return lay if fe.plan().supports_layout(lay) else mlib.LOGMEL_REF
+
     marks, pending = [], []
     pool = [[ev() for _ in range(9)] for _ in range(a.steps)]   # events are created outside the timed region
 
@@ -242,22 +254,23 @@ def main():
         with torch.no_grad():
             evs = pool[len(marks)] if timed else None
             e0, e1, e2 = evs[:3] if timed else (None, None, None)
+            lay = layout_now()
             if timed:
                 e0.record()
             if a.aug:   # negatives = degraded anchors (README triplet design): clips 2, 5, 8, ... of the batch
                 neg = augm.augment_stems({k: v[2::3] for k, v in stems.items()}, decisions=pending.pop() if pending else None)
                 for k in stems:
                     xa[:, 2 * ("vocals", "bass", "drums", "other").index(k):][2::3, :2] = neg[k]
-                feats, logmel = fe.features_and_logmel(stems_aug)
+                feats, logmel = fe.features_and_logmel(stems_aug, lay, lay == mlib.LOGMEL_CM16)
             elif stager is not None:
                 fut = state["fut"]
                 xin = fut.get()
                 state["k"] += 1
                 state["fut"] = stager.submit(host_batches[state["k"] % 2])   # next batch's H2D overlaps this step
-                feats, logmel = fe.features_and_logmel(ingest.stems_views(xin))
+                feats, logmel = fe.features_and_logmel(ingest.stems_views(xin), lay, lay == mlib.LOGMEL_CM16)
                 stager.release(fut)
             else:
-                feats, logmel = fe.features_and_logmel(stems)
+                feats, logmel = fe.features_and_logmel(stems, lay, lay == mlib.LOGMEL_CM16)
             if timed:
                 e1.record()
             if backend == "hip":
@@ -464,7 +477,9 @@ def main():
                        ", InfoNCE on all-gathered embeddings" + (", HIP augmentation chain on the negatives" if a.aug else "") +
                        ("" if a.ingest == "resident" else f"; PCIe-INCLUSIVE: every batch staged from pinned host memory as {a.ingest}"),
                        "clips_per_gpu": B, "clip_samples": T, "n_fft": n_fft, "hop": hop, "n_mels": n_mels,
-                       "encoder_backend": backend, "conv1_precision": a.precision, "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
+                       "encoder_backend": backend, "conv1_precision": a.precision,
+                       "logmel_layout": {0: "reference (B,8,M,F)", 1: "channel-minor [B][F][M][8] fp32 (encoder-internal)",
+                                         2: "channel-minor float16 hi/lo planes (encoder-internal)"}[layout_now()], "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
             "roofline": roof,
         }
         out["alt"] = alt

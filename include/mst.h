@@ -85,6 +85,32 @@ int mst_melfeat_forward_stems_pcm16(const mst_plan* plan, const int16_t* const s
                                     int B, int T, float* logmel, float* feats, void* workspace,
                                     size_t workspace_bytes, void* stream);
 
+/* Log-mel layouts.  MST_LOGMEL_REF is the reference's tensor (what MelSpectrogramPreprocessor.forward returns,
+ * src/model.py:41-67).  The two channel-minor layouts are the ENCODER-INTERNAL forms: conv1 reads 8-channel patches, and a
+ * (frame, band) holding its 8 channels contiguously (32 bytes fp32; 16 + 16 bytes as float16 high / low parts, x = hi + lo to
+ * 22 significant bits) lets stage A write whole 128-byte lines once and conv1 load 256-byte runs per frame; the float16
+ * form is what the f16 / split-precision convolutions (mst_encoder_set_precision) consume without any conversion pass.  */
+#define MST_LOGMEL_REF 0   /* dev [B][8][n_mels][frames] fp32                                            */
+#define MST_LOGMEL_CM32 1  /* dev [B][frames][n_mels][8] fp32, 16-byte aligned                           */
+#define MST_LOGMEL_CM16 2  /* dev [B][frames][n_mels][8] float16, twice: high parts and low parts        */
+/* 1 if stage A writes `layout` directly for this plan (the sliding-window kernels: n_fft 1024 / hop 256 and n_fft 2048 /
+ * hop 512), else 0: ask for MST_LOGMEL_REF then.                                                                      */
+int mst_plan_layout_supported(const mst_plan* plan, int layout);
+typedef struct mst_melfeat_io {
+  const void* stems4[4];  /* dev, per stem [B][2][T]: fp32, or int16 PCM when pcm16 != 0 (as the entry points above) */
+  long long clip_stride;  /* samples between consecutive clips of one stem                                          */
+  int32_t pcm16;
+  int32_t layout;         /* MST_LOGMEL_*: layout of `logmel`                                                        */
+  void* logmel;           /* dev, may be NULL (features only)                                                        */
+  void* logmel_lo;        /* dev, MST_LOGMEL_CM16 only: the low parts                                                 */
+  uint32_t* absmax;       /* optional dev [B]: max |log-mel| of every clip as float bits (zeroed by the call) -- the    */
+                          /* range bound of the float16 convolutions, so that no separate pass reads the log-mel      */
+  float* feats;           /* dev [B][feature_dim], may be NULL                                                       */
+} mst_melfeat_io;
+/* The same launch as mst_melfeat_forward_stems[_pcm16] with the log-mel in any of the layouts above.                  */
+int mst_melfeat_forward_io(const mst_plan* plan, const mst_melfeat_io* io, int B, int T, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Stage B: FiLM MLP + band-split Conv2D/BN/FiLM/ReLU/MaxPool x2 + attention pooling (eval).
  * Replaces: MixingFeatureEncoder.forward src/model.py:410-464, SubSpectrogramCNN.forward
@@ -144,6 +170,24 @@ size_t mst_encoder_workspace_bytes(const mst_encoder* enc, int B, int frames);
 int mst_encoder_forward(const mst_encoder* enc, const float* logmel, int frames, const float* feats,
                         int B, float* emb, const mst_encoder_taps* taps, void* workspace,
                         size_t workspace_bytes, void* stream);
+
+/* The same forward with the log-mel in one of the encoder-internal channel-minor layouts that stage A writes directly
+ * (MST_LOGMEL_*, mst_melfeat_forward_io): MST_LOGMEL_CM32 for the exact-fp32 conv1 (20-mel sub-bands, or an even
+ * split_size below 20), MST_LOGMEL_CM16 (high + low float16 planes; the plain-f16 mode 3 reads the high parts only) for
+ * the f16 / split-precision modes of mst_encoder_set_precision.  mst_encoder_layout_supported answers for the encoder's
+ * CURRENT precision mode.  absmax: stage A's per-clip max |log-mel| (float bits) -- required with MST_LOGMEL_CM16 in the
+ * modes that run conv2 on float16 as well (2, 3), optional otherwise (it saves the pass that derives it).          */
+typedef struct mst_logmel_in {
+  int32_t layout;          /* MST_LOGMEL_*                                     */
+  int32_t pad_;
+  const void* data;        /* dev: the log-mel (MST_LOGMEL_CM16: high parts)   */
+  const void* lo;          /* dev: MST_LOGMEL_CM16 low parts, else NULL        */
+  const uint32_t* absmax;  /* dev [B] or NULL                                  */
+} mst_logmel_in;
+int mst_encoder_layout_supported(const mst_encoder* enc, int layout);
+int mst_encoder_forward_in(const mst_encoder* enc, const mst_logmel_in* logmel, int frames, const float* feats,
+                           int B, float* emb, const mst_encoder_taps* taps, void* workspace,
+                           size_t workspace_bytes, void* stream);
 
 /* Training forward (first half): the same network with train-mode BatchNorm -- batch statistics over
  * (B, H, W) per (sub-band, channel), biased variance, as nn.BatchNorm2d in training mode (src/model.py:107-125 under

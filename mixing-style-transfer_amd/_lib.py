@@ -39,6 +39,20 @@ class EncoderTaps(C.Structure):
     _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("events", C.c_void_p * 6)]
 
 
+# log-mel layouts (include/mst.h MST_LOGMEL_*)
+LOGMEL_REF, LOGMEL_CM32, LOGMEL_CM16 = 0, 1, 2
+
+
+class MelfeatIO(C.Structure):
+    _fields_ = [("stems4", C.c_void_p * 4), ("clip_stride", C.c_longlong), ("pcm16", C.c_int32), ("layout", C.c_int32),
+                ("logmel", C.c_void_p), ("logmel_lo", C.c_void_p), ("absmax", C.c_void_p), ("feats", C.c_void_p)]
+
+
+class LogmelIn(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("pad_", C.c_int32), ("data", C.c_void_p), ("lo", C.c_void_p),
+                ("absmax", C.c_void_p)]
+
+
 class EncoderTrainTaps(C.Structure):
     _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("bn1", C.c_void_p),
                 ("bn2", C.c_void_p), ("film_in", C.c_void_p), ("drop1_mask", C.c_void_p), ("drop1_scale", C.c_float),
@@ -72,6 +86,12 @@ SYMBOLS = {
                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_melfeat_forward_stems_pcm16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_longlong, C.c_int, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_plan_layout_supported": (C.c_int, [C.c_void_p, C.c_int]),
+    "mst_melfeat_forward_io": (C.c_int, [C.c_void_p, C.POINTER(MelfeatIO), C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                         C.c_void_p]),
+    "mst_encoder_layout_supported": (C.c_int, [C.c_void_p, C.c_int]),
+    "mst_encoder_forward_in": (C.c_int, [C.c_void_p, C.POINTER(LogmelIn), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                         C.POINTER(EncoderTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_encoder_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(EncoderConfig), C.POINTER(EncoderWeights)]),
     "mst_encoder_destroy": (None, [C.c_void_p]),
     "mst_encoder_set_precision": (C.c_int, [C.c_void_p, C.c_int]),

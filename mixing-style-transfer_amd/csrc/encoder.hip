@@ -17,6 +17,7 @@
 #include "common.h"
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -193,6 +194,11 @@ struct ConvParams {
   // and the batch statistics are those of the stored values.  NULL: fp32 yraw.
   _Float16* yraw16;
   const float* y_scale;
+  // conv1 with a CHANNEL-MINOR log-mel (mst.h MST_LOGMEL_CM32 / CM16; LAY template argument of the conv1 kernels):
+  // `in` (and in_lo) = [B][frames][cm_mels][8 ch]; a band's rows start at mel row band * cm_overlap; in_clipstride is in
+  // elements of the layout's 16-byte units' scalar type (floats: frames * cm_mels * 8)
+  const void* in_lo;
+  int cm_mels, cm_overlap;
 };
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
@@ -555,16 +561,21 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 // of one wave overlaps the MFMAs of its SIMD partner.  Workgroups own contiguous runs of sets, so the band (and
 // with it the LDS weight image) changes at most once per workgroup.
 // ------------------------------------------------------------------------------------------
-template <int SUB, int MODE = 0>
+// LAY 0: log-mel in the reference layout (B, 8, M, F): one 64-lane row load per (channel, patch row), 64 per tile.
+// LAY 1: channel-minor log-mel [B][F][M][8] (MST_LOGMEL_CM32): a frame of the patch -- 8 mel rows x 8 channels -- is 256
+//        contiguous bytes; a lane loads 16-byte units (frame, row, half = 4 channels), 12 per tile, every lane busy, and
+//        scatters them into the same channel-major LDS patch (4 ds_write_b32 per unit, 2-way bank conflicts at most).
+template <int SUB, int MODE = 0, int LAY = 0>
 __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const ConvParams p) {
   using C = CC<1, SUB>;
   constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
   static_assert(C::RL == 64, "resident conv1 expects one loader row per instruction");
+  static_assert(LAY == 0 || PR == 8, "the channel-minor loader maps lane bits 1..3 to the 8 patch rows");
   constexpr int WCH = 49 * NT * 64;                  // floats per 4-channel weight chunk
   constexpr int WBP = ConvGeom<1, SUB>::WBP;         // chunk pitch in global memory
   constexpr int CHS = PR * PC;                       // floats per patch channel
   constexpr int PATCH = 8 * CHS;                     // 8 input channels
-  constexpr int NPF = 8 * PR;                        // one 64-lane row load per (channel, row)
+  constexpr int NPF = LAY == 0 ? 8 * PR : (PC + 3) / 4;   // LAY 0: one 64-lane row load per (channel, row); LAY 1: 4 frames per load
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -597,29 +608,53 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
     abase[t] = kq * CHS + (pos / 5) * PC + 5 * (C::WPG * ag + wv) + pos % 5;
   }
 
-  float pf[NPF];
-  unsigned long long rowmask = 0;
-  bool col_ok = false;
+  typename std::conditional<LAY == 0, float, f32x4>::type pf[NPF];
+  unsigned long long rowmask = 0;   // LAY 0: bit i = row of piece i inside the band (wave-uniform); LAY 1: bit i = this lane's unit of piece i inside
+  bool col_ok = false;              // LAY 0: this lane's column inside the clip; LAY 1: this lane's row inside the band
   int coff = 0, nrow0 = 0, nvalid = 0;
   const float* nsrc = p.in;
+  // LAY 1: lane = 16 fq + 2 r + half -> patch row r, channels 4 half .. 4 half + 3, frames fq + 4 i (piece i)
+  const int lr = (lane >> 1) & 7, lhalf = lane & 1, lfq = lane >> 4;
+  const unsigned frame_bytes = (unsigned)p.cm_mels * 32u;
   auto prefetch_setup = [&](const Tile& t) __attribute__((always_inline)) {
     nrow0 = C::TROWS * t.tr - 3;
-    const int col0 = C::TCOLS * t.tc - 3, cin = col0 + lane;
     nvalid = t.valid;
-    nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
-    col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
-    coff = min(max(cin, 0), p.in_cols - 1);
     rowmask = 0;
+    if constexpr (LAY == 0) {
+      const int col0 = C::TCOLS * t.tc - 3, cin = col0 + lane;
+      nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
+      col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
+      coff = min(max(cin, 0), p.in_cols - 1);
+    } else {
+      const int rin = nrow0 + lr, rc = min(max(rin, 0), p.in_rows - 1);
+      nsrc = p.in + (size_t)t.clip * p.in_clipstride;                       // wave-uniform clip base
+      col_ok = nvalid && rin == rc;
+      coff = ((t.band * p.cm_overlap + rc) * 8 + 4 * lhalf) * 4;             // byte offset of this lane's (row, half) inside a frame
+      nrow0 = C::TCOLS * t.tc - 3 + lfq;                                     // (re-used: first frame of this lane)
+    }
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
     if (i < NPF) {
-      const int cc = i / PR, r = i % PR;
-      const int rin = nrow0 + r;
-      const int rc = min(max(rin, 0), p.in_rows - 1);
-      if (nvalid && rin == rc) rowmask |= 1ull << i;
-      const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols;
-      pf[i] = rowp[coff];
+      if constexpr (LAY == 0) {
+        const int cc = i / PR, r = i % PR;
+        const int rin = nrow0 + r;
+        const int rc = min(max(rin, 0), p.in_rows - 1);
+        if (nvalid && rin == rc) rowmask |= 1ull << i;
+        const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols;
+        pf[i] = rowp[coff];
+      } else {
+        const int fin = nrow0 + 4 * i, fc = min(max(fin, 0), p.in_cols - 1);
+        if (col_ok && fin == fc) rowmask |= 1ull << i;
+        const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
+        pf[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(nsrc) + boff);
+      }
     }
+  };
+  // pieces of the next tile are fetched between the MFMAs of the k-steps: LAY 0 one row per step for the first 64 steps,
+  // LAY 1 one 16-byte unit every 8th step
+  auto prefetch_step = [&](int ks) __attribute__((always_inline)) {
+    if constexpr (LAY == 0) prefetch_piece(ks);
+    else if (ks % 8 == 0) prefetch_piece(ks / 8);
   };
 
   f32x4 acc[MT][NT];
@@ -645,9 +680,21 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
       cur_band = cur.band;
     }
     // stage this wave's prefetched patch (wave-private: no barrier)
+    if constexpr (LAY == 0) {
 #pragma unroll
-    for (int i = 0; i < NPF; ++i)
-      if (lane < PC) pbuf[i * PC + lane] = (((rowmask >> i) & 1ull) && col_ok) ? pf[i] : 0.f;
+      for (int i = 0; i < NPF; ++i)
+        if (lane < PC) pbuf[i * PC + lane] = (((rowmask >> i) & 1ull) && col_ok) ? pf[i] : 0.f;
+    } else {
+      float* pl = pbuf + (4 * lhalf) * CHS + lr * PC + lfq;
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        if (4 * i + 3 < PC || 4 * i + lfq < PC) {
+          const bool ok = (rowmask >> i) & 1ull;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) pl[k * CHS + 4 * i] = ok ? pf[i][k] : 0.f;
+        }
+      }
+    }
     nxt = decode(s + 1);
     prefetch_setup(nxt);
     if (!cur.valid) {  // ragged tail of the band: nothing to compute, but keep the prefetch chain alive
@@ -680,7 +727,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
             if (i < NT) b[nx][i] = wres[ch * WCH + (tap * NT + i) * 64 + lane];
             else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
           }
-          if (i == MT + NT) prefetch_piece(ks);
+          if (i == MT + NT) prefetch_step(ks);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -828,15 +875,21 @@ constexpr int kF16Steps = 13;         // ceil(49 taps / 4)
 // accumulate -- the arithmetic of the reference's `--use_amp` autocast convolutions (src/train.py:251-253), opt-in.
 // MODE 1 (training forward, TERMS = 1): raw convolution output + bias in accumulator order and the batch-statistics sums,
 // exactly as conv1_resident_kernel<SUB, 1> leaves them.
-template <int SUB, int TERMS, int MODE = 0>
+// LAY 0: fp32 log-mel in the reference layout, converted to float16 hi / lo while it is staged (64 row loads and ~700 vector
+//        instructions per tile: more time than the MFMAs of the plain-f16 mode).
+// LAY 2: the log-mel arrives from stage A as float16 hi / lo planes, channel-minor [B][F][M][8] (MST_LOGMEL_CM16): a patch
+//        position IS one 16-byte vector of the LDS image -- 6 (+ 6 low-part) loads and as many ds_write_b128 per tile, no
+//        conversion, the same bits as LAY 0 produces.
+template <int SUB, int TERMS, int MODE = 0, int LAY = 0>
 __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16,
                                                                   _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo) {
   using C = CC<1, SUB>;
   constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
   static_assert(C::RL == 64, "one loader row per instruction");
+  static_assert(LAY == 0 || (LAY == 2 && PR == 8), "the channel-minor loader maps lane bits 0..2 to the 8 patch rows");
   constexpr int WVEC = kF16Steps * NT * 2 * 64;      // h16x8 vectors of one band's weights: [step][nt][hi/lo][lane]
   constexpr int PVEC = PR * PC;                      // positions per patch (one h16x8 = 8 channels each)
-  constexpr int NPF = 8 * PR;
+  constexpr int NPF = LAY == 0 ? 8 * PR : (PC + 7) / 8;   // LAY 2: 8 frames x 8 rows per load instruction
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -876,27 +929,50 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
     toff[st] = (tap / 7) * PC + tap % 7;
   }
 
-  float pf[NPF];
-  unsigned long long rowmask = 0;
-  bool col_ok = false;
+  typename std::conditional<LAY == 0, float, h16x8>::type pf[NPF];
+  h16x8 pfl[LAY == 0 ? 1 : NPF];     // LAY 2, TERMS 3: the low parts
+  unsigned long long rowmask = 0;    // LAY 0: bit i = row of piece i inside the band (wave-uniform); LAY 2: bit i = this lane's position of piece i inside
+  bool col_ok = false;               // LAY 0: this lane's column inside the clip; LAY 2: this lane's row inside the band
   int coff = 0, nrow0 = 0, nvalid = 0;
   const float* nsrc = p.in;
+  const char* nsrc_lo = static_cast<const char*>(p.in_lo);
+  // LAY 2: lane = 8 fq + r -> patch row r, frames fq + 8 i (piece i)
+  const int lr = lane & 7, lfq = lane >> 3;
+  const unsigned frame_bytes = (unsigned)p.cm_mels * 16u;
   auto prefetch_setup = [&](const Tile& t) __attribute__((always_inline)) {
     nrow0 = C::TROWS * t.tr - 3;
-    const int cin = C::TCOLS * t.tc - 3 + lane;
     nvalid = t.valid;
-    nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
-    col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
-    coff = min(max(cin, 0), p.in_cols - 1);
     rowmask = 0;
+    if constexpr (LAY == 0) {
+      const int cin = C::TCOLS * t.tc - 3 + lane;
+      nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff;
+      col_ok = lane < PC && cin >= 0 && cin < p.in_cols;
+      coff = min(max(cin, 0), p.in_cols - 1);
+    } else {
+      const int rin = nrow0 + lr, rc = min(max(rin, 0), p.in_rows - 1);
+      const size_t cb = (size_t)t.clip * p.in_clipstride * 2;               // bytes: in_clipstride counts float16 elements
+      nsrc = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.in) + cb);   // wave-uniform clip base (high parts)
+      nsrc_lo = static_cast<const char*>(p.in_lo) + cb;
+      col_ok = nvalid && rin == rc;
+      coff = (t.band * p.cm_overlap + rc) * 16;                              // byte offset of this lane's row inside a frame
+      nrow0 = C::TCOLS * t.tc - 3 + lfq;                                     // (re-used: first frame of this lane)
+    }
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
     if (i < NPF) {
-      const int cc = i / PR, r = i % PR;
-      const int rin = nrow0 + r;
-      const int rc = min(max(rin, 0), p.in_rows - 1);
-      if (nvalid && rin == rc) rowmask |= 1ull << i;
-      pf[i] = (nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[coff];
+      if constexpr (LAY == 0) {
+        const int cc = i / PR, r = i % PR;
+        const int rin = nrow0 + r;
+        const int rc = min(max(rin, 0), p.in_rows - 1);
+        if (nvalid && rin == rc) rowmask |= 1ull << i;
+        pf[i] = (nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols)[coff];
+      } else {
+        const int fin = nrow0 + 8 * i, fc = min(max(fin, 0), p.in_cols - 1);
+        if (col_ok && fin == fc) rowmask |= 1ull << i;
+        const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
+        pf[i] = *reinterpret_cast<const h16x8*>(reinterpret_cast<const char*>(nsrc) + boff);
+        if (TERMS == 3) pfl[i] = *reinterpret_cast<const h16x8*>(nsrc_lo + boff);
+      }
     }
   };
 
@@ -920,8 +996,18 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
       __syncthreads();
       cur_band = cur.band;
     }
-    // stage the prefetched fp32 patch as f16 hi / lo, channel-minor: one 16-byte vector per position
-    if (lane < PC) {
+    // stage the prefetched patch as f16 hi / lo, channel-minor: one 16-byte vector per position
+    if constexpr (LAY == 2) {
+      const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) {
+        if (8 * i + 7 < PC || 8 * i + lfq < PC) {
+          const bool ok = (rowmask >> i) & 1ull;
+          phi[lr * PC + lfq + 8 * i] = ok ? pf[i] : z;
+          if (TERMS == 3) plo[lr * PC + lfq + 8 * i] = ok ? pfl[i] : z;
+        }
+      }
+    } else if (lane < PC) {
 #pragma unroll
       for (int r = 0; r < PR; ++r) {
         h16x8 vh, vl;
@@ -976,8 +1062,12 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
             if (TERMS == 3) al[nx][t] = plo[abase[t] + toff[st + 1]];
           }
         }
+        if constexpr (LAY == 0) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) prefetch_piece(st * 5 + k);   // 64 row loads of the next tile over 13 steps
+          for (int k = 0; k < 5; ++k) prefetch_piece(st * 5 + k);   // 64 row loads of the next tile over 13 steps
+        } else {
+          if (st % 2 == 0) prefetch_piece(st / 2);                  // 6 (+ 6) 16-byte loads over 13 steps
+        }
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -2644,9 +2734,37 @@ size_t mst_encoder_workspace_bytes(const mst_encoder* e, int B, int frames) {
   return ws_layout(e, B, frames).total;
 }
 
+static bool conv1_resident_geometry(const mst_encoder* e) {
+  return (e->sub == 2 || (e->sub == 1 && e->cfg.split_size % 2 == 0)) && !getenv("MST_CONV1_CHUNKED");
+}
+
+int mst_encoder_layout_supported(const mst_encoder* e, int layout) {
+  if (!e) return 0;
+  if (layout == MST_LOGMEL_REF) return 1;
+  if (layout == MST_LOGMEL_CM32) return e->conv1_f16x3 == 0 && conv1_resident_geometry(e);
+  if (layout == MST_LOGMEL_CM16) return e->conv1_f16x3 != 0;
+  return 0;
+}
+
 int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
                         const mst_encoder_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(e && logmel && feats && emb, "mst_encoder_forward: NULL argument");
+  mst_logmel_in in{};
+  in.layout = MST_LOGMEL_REF, in.data = logmel;
+  return mst_encoder_forward_in(e, &in, frames, feats, B, emb, taps, workspace, workspace_bytes, stream);
+}
+
+int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int frames, const float* feats, int B, float* emb,
+                           const mst_encoder_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && lin && lin->data && feats && emb, "mst_encoder_forward: NULL argument");
+  const int lay = lin->layout;
+  MST_REQUIRE(mst_encoder_layout_supported(e, lay),
+              "mst_encoder_forward: log-mel layout %d does not fit this encoder's conv1 kernel (precision mode %d; query "
+              "mst_encoder_layout_supported)", lay, e->conv1_f16x3);
+  MST_REQUIRE(lay != MST_LOGMEL_CM16 || e->conv1_f16x3 == 3 || lin->lo, "mst_encoder_forward: MST_LOGMEL_CM16 needs the low parts in the split-precision modes");
+  MST_REQUIRE(lay != MST_LOGMEL_CM16 || e->conv1_f16x3 < 2 || lin->absmax, "mst_encoder_forward: MST_LOGMEL_CM16 needs absmax (stage A's per-clip max |log-mel|) when conv2 runs on float16 too");
+  MST_REQUIRE(lay == MST_LOGMEL_REF || ((reinterpret_cast<uintptr_t>(lin->data) | reinterpret_cast<uintptr_t>(lin->lo)) & 15) == 0,
+              "mst_encoder_forward: channel-minor log-mel must be 16-byte aligned");
+  const float* logmel = static_cast<const float*>(lin->data);
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
   const WsLayout L = ws_layout(e, B, frames);
   MST_REQUIRE(L.W2 >= 1, "mst_encoder_forward: clip too short for two pooling stages (frames=%d)", frames);
@@ -2683,6 +2801,7 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
     cp.in_cstride = e->cfg.n_mels * frames;
     cp.in_bandoff = e->cfg.overlap * frames;
     cp.in_clipstride = (long long)8 * e->cfg.n_mels * frames;
+    cp.in_lo = lin->lo, cp.cm_mels = e->cfg.n_mels, cp.cm_overlap = e->cfg.overlap;
     cp.out_rows = e->H1, cp.out_cols = L.W1;
     cp.tiles_r = e->H1;
     cp.tiles_c = e->sub == 2 ? (L.W1 + 7) / 8 : (L.W1 + 15) / 16;
@@ -2706,27 +2825,40 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
         if (err == hipSuccess)
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3, 0, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 0, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
       }
       const bool both = e->conv1_f16x3 >= 2;
       cp.f16_winv = e->f16_winv1;
       if (both && !(taps && taps->pool1)) cp.out = nullptr;   // fp32 pool1 only when a tap asks for it
       if (both) {   // range scale of conv2's f16 input from a rigorous bound (see f16_scale_kernel): no host check, no refusal
-        unsigned* xmax = reinterpret_cast<unsigned*>(ws + L.xmax);
+        const unsigned* xmax = lin->absmax;   // stage A's per-clip max |log-mel|, when the caller has it
         float* fsc = reinterpret_cast<float*>(ws + L.f16scale);
-        MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
-        const long long npc = (long long)8 * e->cfg.n_mels * frames;
-        hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, npc, xmax);
+        if (!xmax) {   // (reference-layout input only, checked above): one more pass over the log-mel
+          unsigned* xm = reinterpret_cast<unsigned*>(ws + L.xmax);
+          MST_HIP_CHECK(hipMemsetAsync(xm, 0, (size_t)B * sizeof(unsigned), st));
+          const long long npc = (long long)8 * e->cfg.n_mels * frames;
+          hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, npc, xm);
+          xmax = xm;
+        }
         hipLaunchKernelGGL(f16_scale_kernel, dim3(B * ns), dim3(64), 0, st, aff1, e->w1norm, xmax, fsc, ns);
         cp.f16_scale = fsc;
       }
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
       _Float16* oh = both ? reinterpret_cast<_Float16*>(ws + L.pool1_h16) : nullptr;
       _Float16* ol = e->conv1_f16x3 == 2 ? reinterpret_cast<_Float16*>(ws + L.pool1_l16) : nullptr;
-      if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
+      if (lay == MST_LOGMEL_CM16) {
+        if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 0, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
+        else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 0, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
+      } else if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       err = hipGetLastError();
-    } else if ((e->sub == 2 || (e->sub == 1 && e->cfg.split_size % 2 == 0)) && !getenv("MST_CONV1_CHUNKED")) {
+    } else if (conv1_resident_geometry(e)) {
       // band-resident kernel on 2 x 40 tiles; 16-mel sub-bands (pool height 1) take it with two 1 x 5 windows per lane
       using C = CC<1, 2>;
       if (e->sub == 1) {
@@ -2741,9 +2873,13 @@ int mst_encoder_forward(const mst_encoder* e, const float* logmel, int frames, c
       if (mst::first_use_on_device(attr_set)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_resident_kernel<2, 0, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 attribute failed: %s", hipGetErrorString(err));
       }
-      hipLaunchKernelGGL((conv1_resident_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp);
+      if (lay == MST_LOGMEL_CM32) hipLaunchKernelGGL((conv1_resident_kernel<2, 0, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
+      else hipLaunchKernelGGL((conv1_resident_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp);
       err = hipGetLastError();
     } else {
       err = e->sub == 2 ? launch_conv<1, 2>(cp, g, st) : launch_conv<1, 1>(cp, g, st);

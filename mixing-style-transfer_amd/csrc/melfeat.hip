@@ -1441,8 +1441,15 @@ size_t mst_melfeat_workspace_bytes(const mst_plan* p, int B, int T) {
 }  // extern "C"
 
 namespace {
+struct LogmelOut {   // where and how the log-mel leaves stage A (mst.h: MST_LOGMEL_*)
+  int layout = MST_LOGMEL_REF;
+  void* lo = nullptr;          // MST_LOGMEL_CM16: low parts
+  unsigned* absmax = nullptr;  // optional [B]
+};
 int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pcm16, long long clip_stride, int B, int T,
-                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream);
+                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream,
+                         const LogmelOut& lo = LogmelOut());
+bool plan_uses_v2(const mst_plan* p);
 }
 
 extern "C" {
@@ -1476,12 +1483,43 @@ int mst_melfeat_forward_stems_pcm16(const mst_plan* p, const int16_t* const stem
   return melfeat_forward_impl(p, four, true, clip_stride, B, T, logmel, feats, workspace, workspace_bytes, stream);
 }
 
+int mst_plan_layout_supported(const mst_plan* p, int layout) {
+  if (!p) return 0;
+  if (layout == MST_LOGMEL_REF) return 1;
+  return (layout == MST_LOGMEL_CM32 || layout == MST_LOGMEL_CM16) && plan_uses_v2(p) ? 1 : 0;
+}
+
+int mst_melfeat_forward_io(const mst_plan* p, const mst_melfeat_io* io, int B, int T, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+  MST_REQUIRE(p && io, "mst_melfeat_forward_io: NULL plan/io");
+  MST_REQUIRE(io->layout >= MST_LOGMEL_REF && io->layout <= MST_LOGMEL_CM16, "mst_melfeat_forward_io: unknown layout %d", io->layout);
+  MST_REQUIRE(mst_plan_layout_supported(p, io->layout),
+              "mst_melfeat_forward_io: layout %d is not available for this plan (n_fft %d, hop %d: query mst_plan_layout_supported)",
+              io->layout, p->n_fft, p->hop);
+  MST_REQUIRE(io->layout != MST_LOGMEL_CM16 || !io->logmel || io->logmel_lo, "mst_melfeat_forward_io: MST_LOGMEL_CM16 needs logmel_lo");
+  MST_REQUIRE(io->layout == MST_LOGMEL_REF || !io->logmel || (reinterpret_cast<uintptr_t>(io->logmel) & 15) == 0,
+              "mst_melfeat_forward_io: channel-minor log-mel must be 16-byte aligned");
+  MST_REQUIRE(io->layout != MST_LOGMEL_CM16 || !io->logmel_lo || (reinterpret_cast<uintptr_t>(io->logmel_lo) & 15) == 0,
+              "mst_melfeat_forward_io: channel-minor log-mel must be 16-byte aligned");
+  LogmelOut lo;
+  lo.layout = io->layout, lo.lo = io->logmel_lo, lo.absmax = io->absmax;
+  const void* four[4] = {io->stems4[0], io->stems4[1], io->stems4[2], io->stems4[3]};
+  return melfeat_forward_impl(p, four, io->pcm16 != 0, io->clip_stride, B, T, static_cast<float*>(io->logmel), io->feats, workspace,
+                              workspace_bytes, stream, lo);
+}
+
 }  // extern "C"
 
 namespace {
 
+bool stage_a_env_old() {
+  const char* which = getenv("MST_STAGE_A");
+  return (which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) || getenv("MST_MELFEAT_GENERIC");
+}
+bool plan_uses_v2(const mst_plan* p) { return (p->v2_ok || p->v4_ok) && !stage_a_env_old(); }
+
 int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pcm16, long long clip_stride, int B, int T,
-                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream) {
+                         float* logmel, float* feats, void* workspace, size_t workspace_bytes, void* stream, const LogmelOut& lmo) {
   MST_REQUIRE(p && stems4[0] && stems4[1] && stems4[2] && stems4[3], "mst_melfeat_forward: NULL plan/stems");
   MST_REQUIRE(clip_stride >= 2LL * T, "mst_melfeat_forward_stems: clip_stride %lld < 2*T", clip_stride);
   MST_REQUIRE(B > 0 && T > p->n_fft / 2, "mst_melfeat_forward: need B>0 and T > n_fft/2 (reflect pad); B=%d T=%d", B, T);
@@ -1522,13 +1560,18 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
   MST_REQUIRE(lds <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds);
   hipError_t e = hipErrorInvalidValue;
   // sliding-window kernel for the standard configuration (MST_STAGE_A=spw | generic selects the older kernels)
-  const char* which = getenv("MST_STAGE_A");
-  const bool use_v2 = p->v2_ok && !(which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) && !getenv("MST_MELFEAT_GENERIC");
-  const bool use_v4 = p->v4_ok && !(which && (!strcmp(which, "spw") || !strcmp(which, "generic"))) && !getenv("MST_MELFEAT_GENERIC");
+  const bool use_v2 = p->v2_ok && !stage_a_env_old();
+  const bool use_v4 = p->v4_ok && !stage_a_env_old();
+  MST_REQUIRE(lmo.layout == MST_LOGMEL_REF || use_v2 || use_v4, "mst_melfeat_forward: channel-minor log-mel needs the sliding-window kernels");
+  if (lmo.absmax) {
+    MST_REQUIRE(lmo.layout != MST_LOGMEL_REF, "mst_melfeat_forward: absmax comes with the channel-minor layouts only");
+    MST_HIP_CHECK(hipMemsetAsync(lmo.absmax, 0, (size_t)B * sizeof(unsigned), st));
+  }
   if (use_v4) {
     K4Params k4{};
     for (int i = 0; i < 4; ++i) k4.stem[i] = stems4[i];
     k4.clip_stride = clip_stride, k4.logmel = logmel, k4.partials = reinterpret_cast<float*>(workspace);
+    k4.out_mode = lmo.layout, k4.logmel_lo = lmo.lo, k4.absmax = lmo.absmax;
     k4.window = p->d_window, k4.tw2 = p->d_v2_tw2, k4.tw3 = p->d_v2_tw3, k4.tw4 = p->d_v4_tw4, k4.segw = p->d_v4_segw;
     k4.pstart = p->d_v4_pstart, k4.pid = p->d_v4_pid, k4.bandtab = p->d_v4_bandtab;
     k4.B = B, k4.T = T, k4.F = F, k4.M = p->n_mels;
@@ -1537,7 +1580,7 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     k4.fpw = v4_fpw(F), k4.runs_per_clip = v4_runs(F), k4.pstride = pstride_of(p);
     kp.runs_per_clip = k4.runs_per_clip;
     const size_t lds4 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows + 16) * 64 + p->v4_segw_count + 1024 + 8 * v4::kScr4) * sizeof(float2) +
-                        (size_t)v4::kWPS * v4::kBLK * 4 * 128 * sizeof(float);
+                        (size_t)v4::kWPS * v4::kBLK * 4 * 128 * sizeof(float) + 16;
     MST_REQUIRE(lds4 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds4);
     const int grid4 = B * k4.runs_per_clip;
     e = pcm16 ? launch_melfeat_v2_2048<short>(k4, grid4, lds4, st) : launch_melfeat_v2_2048<float>(k4, grid4, lds4, st);
@@ -1545,6 +1588,7 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     K2Params k2{};
     for (int i = 0; i < 4; ++i) k2.stem[i] = stems4[i];
     k2.clip_stride = clip_stride, k2.logmel = logmel, k2.partials = reinterpret_cast<float*>(workspace);
+    k2.out_mode = lmo.layout, k2.logmel_lo = lmo.lo, k2.absmax = lmo.absmax;
     k2.window = p->d_window, k2.tw2 = p->d_v2_tw2, k2.tw3 = p->d_v2_tw3, k2.segw = p->d_v2_segw;
     k2.segstart = p->d_v2_segstart, k2.segid = p->d_v2_segid, k2.bandtab = p->d_v2_bandtab, k2.maxcnt = p->v2_maxcnt;
     k2.B = B, k2.T = T, k2.F = F, k2.M = p->n_mels;
@@ -1555,7 +1599,7 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     const int wps = p->v2_wps;
     const bool wide = p->n_mels > 128;   // 4 bands per lane, 4-frame blocks
     const size_t lds2 = (size_t)((mstpk::kTw2Rows + mstpk::kTw3Rows) * 64 + p->v2_segw_count + 4 * wps * mstpk::kScr) * sizeof(float2) +
-                        (size_t)(wps * (wide ? 4 : (wps == 2 ? 8 : 4)) * 4 * (wide ? 256 : 128) + 1024) * sizeof(float);
+                        (size_t)(wps * (wide ? 4 : (wps == 2 ? 8 : 4)) * 4 * (wide ? 256 : 128) + 1024) * sizeof(float) + 16;
     MST_REQUIRE(lds2 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds2);
     const int grid2 = B * k2.runs_per_clip;
     if (wide) e = pcm16 ? launch_melfeat_v2<short, 2, 4>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 2, 4>(k2, grid2, lds2, st);

@@ -63,6 +63,22 @@ def melscale_fbanks_htk(n_freqs: int, n_mels: int, sample_rate: int) -> torch.Te
     return torch.max(torch.zeros(1), torch.min(lower, upper))
 
 
+class LogMel:
+    """A log-mel batch in one of the ENCODER-INTERNAL channel-minor layouts that stage A writes directly (include/mst.h
+    MST_LOGMEL_CM32 / CM16): `data` (B, frames, n_mels, 8) fp32, or float16 high parts with the low parts in `lo`;
+    `absmax` (B,) int32 = max |log-mel| per clip as float bits (the range bound of the float16 convolutions).  Only
+    `HipEncoder.forward` consumes it; `to_reference()` gives the reference's (B, 8, n_mels, frames) tensor."""
+
+    def __init__(self, layout, data, lo=None, absmax=None):
+        self.layout, self.data, self.lo, self.absmax = layout, data, lo, absmax
+        self.B, self.frames, self.n_mels = data.shape[0], data.shape[1], data.shape[2]
+        self.device = data.device
+
+    def to_reference(self):
+        x = self.data.float() if self.lo is None else self.data.float() + self.lo.float()
+        return x.permute(0, 3, 2, 1).contiguous()
+
+
 class MelFeatPlan:
     """Owns an `mst_plan` (device tables for one STFT/mel configuration) and a cached workspace."""
 
@@ -97,9 +113,39 @@ class MelFeatPlan:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws, need
 
-    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True):
+    def supports_layout(self, layout) -> bool:
+        """Whether stage A writes `layout` (_lib.LOGMEL_*) directly for this configuration."""
+        return bool(_lib.lib().mst_plan_layout_supported(self._h, int(layout)))
+
+    def _run(self, ptrs4, stride, pcm16, B, T, dev, want_logmel, want_feats, layout, want_absmax):
+        F = self.frames(T)
+        logmel = lo = absmax = None
+        if want_logmel:
+            if layout == _lib.LOGMEL_REF:
+                logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=dev)
+            elif layout == _lib.LOGMEL_CM32:
+                logmel = torch.empty(B, F, self.n_mels, 8, dtype=torch.float32, device=dev)
+            else:
+                logmel = torch.empty(B, F, self.n_mels, 8, dtype=torch.float16, device=dev)
+                lo = torch.empty_like(logmel)
+            if want_absmax and layout != _lib.LOGMEL_REF:
+                absmax = torch.empty(B, dtype=torch.int32, device=dev)
+        feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=dev) if want_feats else None
+        ws, need = self._workspace(B, T, dev)
+        io = _lib.MelfeatIO((C.c_void_p * 4)(*ptrs4), stride, int(pcm16), int(layout), _lib.dptr(logmel), _lib.dptr(lo),
+                            _lib.dptr(absmax), _lib.dptr(feats))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mst_melfeat_forward_io(self._h, C.byref(io), B, T, _lib.dptr(ws), need,
+                                                          _lib.stream_ptr(dev)), "mst_melfeat_forward_io")
+        if logmel is not None and layout != _lib.LOGMEL_REF:
+            logmel = LogMel(layout, logmel, lo, absmax)
+        return logmel, feats
+
+    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True, layout=_lib.LOGMEL_REF, want_absmax=False):
         """{stem: (B,2,T) | (2,T)} fp32 CUDA -> (logmel, feats) without concatenating the stems: the kernel reads the
-        four tensors in place (views of one packed (B,8,T) tensor work too, any common clip stride)."""
+        four tensors in place (views of one packed (B,8,T) tensor work too, any common clip stride).
+        layout: _lib.LOGMEL_REF -> the reference's (B, 8, n_mels, frames) tensor; LOGMEL_CM32 / CM16 -> a `LogMel` in the
+        encoder-internal channel-minor layout (check `supports_layout` first)."""
         parts = [stems_dict[s] for s in STEMS]
         if parts[0].dim() == 2:
             parts = [q.unsqueeze(0) for q in parts]
@@ -112,40 +158,34 @@ class MelFeatPlan:
             and dt in (torch.float32, torch.int16)
         if not ok:
             if all(q.dtype == torch.int16 for q in parts):
-                return self.forward(torch.cat(parts, dim=1), want_logmel, want_feats)
-            return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats)
-        dev = parts[0].device
-        F = self.frames(T)
-        logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=dev) if want_logmel else None
-        feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=dev) if want_feats else None
-        ws, need = self._workspace(B, T, dev)
-        ptrs = (C.c_void_p * 4)(*[q.data_ptr() for q in parts])
+                return self.forward(torch.cat(parts, dim=1), want_logmel, want_feats, layout, want_absmax)
+            return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats, layout, want_absmax)
         stride = parts[0].stride(0) if B > 1 else 2 * T
-        L = _lib.lib()
-        fn = L.mst_melfeat_forward_stems_pcm16 if dt == torch.int16 else L.mst_melfeat_forward_stems
-        with torch.cuda.device(dev):
-            _lib.check(fn(self._h, ptrs, stride, B, T, _lib.dptr(logmel), _lib.dptr(feats), _lib.dptr(ws), need,
-                          _lib.stream_ptr(dev)), "mst_melfeat_forward_stems")
-        return logmel, feats
+        return self._run([q.data_ptr() for q in parts], stride, dt == torch.int16, B, T, parts[0].device, want_logmel,
+                         want_feats, layout, want_absmax)
 
-    def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True):
-        """stems8 (B, 8, T) CUDA, fp32 or int16 PCM (value = s / 32768) -> (logmel (B,8,M,F) | None, feats (B,Fd) | None)."""
+    def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True, layout=_lib.LOGMEL_REF, want_absmax=False):
+        """stems8 (B, 8, T) CUDA, fp32 or int16 PCM (value = s / 32768) -> (logmel (B,8,M,F) | LogMel | None, feats (B,Fd) | None)."""
         if not stems8.is_cuda:
             raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
         pcm16 = stems8.dtype == torch.int16
         x = stems8.contiguous() if pcm16 else stems8.contiguous().float()
         B, ch, T = x.shape
         assert ch == 8, "expected 8 channels (4 stems x stereo)"
-        F = self.frames(T)
-        logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=x.device) if want_logmel else None
-        feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=x.device) if want_feats else None
-        ws, need = self._workspace(B, T, x.device)
-        L = _lib.lib()
-        fn = L.mst_melfeat_forward_pcm16 if pcm16 else L.mst_melfeat_forward
-        with torch.cuda.device(x.device):
-            _lib.check(fn(self._h, _lib.dptr(x), B, T, _lib.dptr(logmel), _lib.dptr(feats), _lib.dptr(ws), need,
-                          _lib.stream_ptr(x.device)), "mst_melfeat_forward")
-        return logmel, feats
+        if layout == _lib.LOGMEL_REF and not want_absmax:   # the packed-tensor entry points of the C ABI
+            F = self.frames(T)
+            logmel = torch.empty(B, 8, self.n_mels, F, dtype=torch.float32, device=x.device) if want_logmel else None
+            feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=x.device) if want_feats else None
+            ws, need = self._workspace(B, T, x.device)
+            L = _lib.lib()
+            fn = L.mst_melfeat_forward_pcm16 if pcm16 else L.mst_melfeat_forward
+            with torch.cuda.device(x.device):
+                _lib.check(fn(self._h, _lib.dptr(x), B, T, _lib.dptr(logmel), _lib.dptr(feats), _lib.dptr(ws), need,
+                              _lib.stream_ptr(x.device)), "mst_melfeat_forward")
+            return logmel, feats
+        es = x.element_size()
+        return self._run([x.data_ptr() + 2 * s * T * es for s in range(4)], 8 * T, pcm16, B, T, x.device, want_logmel,
+                         want_feats, layout, want_absmax)
 
 
 def stems_to_tensor(stems_dict) -> torch.Tensor:
@@ -200,9 +240,10 @@ class MixingFeatureExtractor:
                                      self.n_spectral_bins if self.use_detailed_spectral else 0)
         return self._plan
 
-    def features_and_logmel(self, stems_dict):
-        """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F))."""
-        lm, f = self.plan().forward_stems(stems_dict, True, True)
+    def features_and_logmel(self, stems_dict, layout=_lib.LOGMEL_REF, want_absmax=False):
+        """One pass over the waveform: returns (features (B,Fd), logmel (B,8,M,F)); with a channel-minor `layout`
+        (_lib.LOGMEL_CM32 / CM16) the log-mel is a `LogMel` in the encoder-internal layout instead."""
+        lm, f = self.plan().forward_stems(stems_dict, True, True, layout, want_absmax)
         return f, lm
 
     def resolve_features(self, stems_dict, features):
@@ -306,10 +347,13 @@ class AudioAugmenter:
         st.bw_sos[:] = sos.reshape(-1).tolist()
         tr["cutoff"] = cutoff.item()
 
-    def _make_ir(self, decay=0.5):
+    def _make_ir(self, decay=0.5, trace=None):
         n = int(self.sr * decay)
         t = torch.linspace(0, decay, n)
-        return torch.exp(-t / (decay / 4)) * torch.randn(n) * 0.1
+        r = torch.randn(n)   # the reference's draw (src/mixing_utils.py:463), global torch CPU generator
+        if trace is not None:
+            trace["reverb_randn"] = r
+        return torch.exp(-t / (decay / 4)) * r * 0.1
 
     def _draw_clip(self, clip):
         trace = {}
@@ -331,7 +375,7 @@ class AudioAugmenter:
         ir = None
         if torch.rand(1) < self.prob:
             clip.reverb = 1
-            ir = self._make_ir()
+            ir = self._make_ir(trace=trace)
             trace["reverb_ir"] = ir
         return ir, trace
 

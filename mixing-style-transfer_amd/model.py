@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
-from .mixing_utils import (STEMS, MelFeatPlan, detailed_bins_for_feature_dim, hann_window, is_deferred,
+from .mixing_utils import (STEMS, LogMel, MelFeatPlan, detailed_bins_for_feature_dim, hann_window, is_deferred,
                            melscale_fbanks_htk, stems_to_tensor)
 
 
@@ -409,9 +409,27 @@ class HipEncoder:
                 yield "sum", self.stats_view(layer, B, frames)
         return dy, dbn
 
+    def preferred_layout(self):
+        """The log-mel layout this encoder's eval forward reads fastest (_lib.LOGMEL_*): the channel-minor form of its conv1
+        precision when the kernel geometry takes it, else the reference layout."""
+        L = _lib.lib()
+        for lay in ((_lib.LOGMEL_CM16,) if self.mode else (_lib.LOGMEL_CM32,)):
+            if L.mst_encoder_layout_supported(self._h, lay):
+                return lay
+        return _lib.LOGMEL_REF
+
     def forward(self, logmel, feats, taps=False, events=None):
-        """events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
-        B, _, M, Fr = logmel.shape
+        """logmel: (B, 8, n_mels, frames) tensor (reference layout) or a `LogMel` (channel-minor, from stage A).
+        events: optional list of 6 recorded torch.cuda.Event (stage boundaries, see include/mst.h)."""
+        if isinstance(logmel, LogMel):
+            lin = _lib.LogmelIn(logmel.layout, 0, _lib.dptr(logmel.data), _lib.dptr(logmel.lo), _lib.dptr(logmel.absmax))
+            B, Fr = logmel.B, logmel.frames
+            keep = logmel   # noqa: F841  (the tensors stay alive until the launch is queued)
+            logmel = logmel.data
+        else:
+            logmel = logmel.contiguous().float()
+            lin = _lib.LogmelIn(_lib.LOGMEL_REF, 0, _lib.dptr(logmel), None, None)
+            B, _, M, Fr = logmel.shape
         L = _lib.lib()
         need = L.mst_encoder_workspace_bytes(self._h, B, Fr)
         if self._ws is None or self._ws.numel() < need or self._ws.device != logmel.device:
@@ -433,9 +451,9 @@ class HipEncoder:
                 tp.events[i] = ev.cuda_event
             t = C.byref(tp)
         with torch.cuda.device(logmel.device):
-            _lib.check(L.mst_encoder_forward(self._h, _lib.dptr(logmel), Fr, _lib.dptr(feats.contiguous().float()), B,
-                                             _lib.dptr(emb), t, _lib.dptr(self._ws), need,
-                                             _lib.stream_ptr(logmel.device)), "mst_encoder_forward")
+            _lib.check(L.mst_encoder_forward_in(self._h, C.byref(lin), Fr, _lib.dptr(feats.contiguous().float()), B,
+                                                _lib.dptr(emb), t, _lib.dptr(self._ws), need,
+                                                _lib.stream_ptr(logmel.device)), "mst_encoder_forward_in")
         return (emb, out) if taps else emb
 
 
@@ -456,18 +474,14 @@ class DistSync:
 
 _TRAIN_TIMING = bool(os.environ.get("MST_TRAIN_TIMING"))
 _POISON_WS = bool(os.environ.get("MST_POISON_WS"))
-_CONV1_WGRAD_MIOPEN = os.environ.get("MST_CONV1_WGRAD", "") == "miopen"
-# library (MIOpen, via aten.convolution_backward) versions of the three convolution gradients, kept for A/B checks only
-_CONV2_WGRAD_MIOPEN = os.environ.get("MST_CONV2_WGRAD", "") == "miopen"
-_CONV2_DGRAD_MIOPEN = os.environ.get("MST_CONV2_DGRAD", "") == "miopen"
 
 
 class _HipTrunk(torch.autograd.Function):
     """The 11 x [conv -> BatchNorm(batch statistics) -> FiLM -> ReLU -> max-pool] x 2 trunk for training.
     Forward: libmst.so (`mst_encoder_forward_train`, raw conv outputs kept).  Backward: pool / ReLU / FiLM / BatchNorm in
     libmst.so (`mst_encoder_train_backward_apply`), conv2 input gradient (`mst_encoder_train_conv2_dgrad`) and both weight
-    gradients (`mst_encoder_train_conv{1,2}_wgrad`) as hand-written fp32-MFMA kernels.  MST_CONV1_WGRAD / MST_CONV2_WGRAD /
-    MST_CONV2_DGRAD=miopen switch single pieces back to `aten.convolution_backward` for A/B checks."""
+    gradients (`mst_encoder_train_conv{1,2}_wgrad`) as hand-written MFMA kernels.  (The library yardstick for these
+    gradients is `train_backend = "torch"`: the whole encoder on PyTorch-ROCm autograd.)"""
     last_timing = None
 
     @staticmethod
@@ -475,7 +489,10 @@ class _HipTrunk(torch.autograd.Function):
         B, _, M, Fr = logmel.shape
         trunk = (c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)
         enc.update_trunk_params(*trunk)
-        enc._frag_gen = getattr(enc, "_frag_gen", 0) + 1   # which forward's parameters the encoder's weight fragments hold
+        # which forward pass's parameters the encoder's weight fragments hold: a MONOTONIC pass counter names the passes, the
+        # owner is rewritten on every fragment rebuild (forward or backward) and never fed back into the counter
+        enc._gen_counter = getattr(enc, "_gen_counter", 0) + 1
+        enc._frag_owner = enc._gen_counter
         W1 = Fr // 5
         mask = None
         if drop_p > 0.0:
@@ -486,7 +503,7 @@ class _HipTrunk(torch.autograd.Function):
         enc._ws_train = None
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p, sync=sync)
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync = enc, drop_p, (B, Fr), sync
-        ctx.gen, ctx.mode = enc._frag_gen, enc.train_mode
+        ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode
         # (the workspace rides with the saved tensors: autograd releases it with them after a backward that does not retain the graph)
         ctx.save_for_backward(logmel, t["pool1"], mask, enc._ws_train, *trunk)
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
@@ -496,19 +513,17 @@ class _HipTrunk(torch.autograd.Function):
     def backward(ctx, dpool_in, _d1, _d2):
         enc, (B, Fr) = ctx.enc, ctx.dims
         logmel, p1, mask, ws, *trunk = ctx.saved_tensors
-        c1w, c2w = trunk[0], trunk[4]
         if getattr(ctx, "consumed", False):
             raise RuntimeError("HIP training trunk (fp32 mode): second backward() through the same forward pass -- the fp32 kernels "
                                "turn the saved convolution outputs into their gradients IN PLACE; run the forward again, or use "
                                "train_precision='f16x3' / 'f16' (their backward leaves the activations intact)")
         ctx.consumed = ctx.mode == 0
         enc._ws_train = ws                           # this pass's activations
-        if ctx.gen != enc._frag_gen or ctx.mode != enc.train_mode:   # another forward re-swizzled the weight fragments since:
+        if ctx.gen != getattr(enc, "_frag_owner", None) or ctx.mode != enc.train_mode:   # another pass re-swizzled the fragments since:
             enc.set_train_precision({v: k for k, v in enc.TRAIN_MODES.items()}[ctx.mode])   # put this pass's parameters back
             enc.update_trunk_params(*trunk)
-            enc._frag_gen = ctx.gen
-        ns, ov, sp = enc.n_sub, enc.overlap, enc.split
-        bw = torch.ops.aten.convolution_backward
+            enc._frag_owner = ctx.gen
+        ns = enc.n_sub
         marks = []
 
         def mark(name):   # MST_TRAIN_TIMING=1: per-section GPU times of the last backward in _HipTrunk.last_timing
@@ -521,44 +536,15 @@ class _HipTrunk(torch.autograd.Function):
         sync = ctx.sync
         dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr, sync=sync)
         mark("apply_bwd2")
-        gi, gw2, gb2 = [], [], []
-        native_w2, native_d2 = not _CONV2_WGRAD_MIOPEN, not _CONV2_DGRAD_MIOPEN
-        if getattr(enc, "train_f16", False):   # the library A/B switches exist for the fp32 kernels only
-            native_w2 = native_d2 = True
-        if not (native_w2 and native_d2):
-            for i in range(ns):
-                a, b, c = bw(dy2[i], p1[:, i].contiguous(), c2w[i], [64], [1, 1], [3, 3], [1, 1], False, [0, 0], 1,
-                             [not native_d2, not native_w2, not native_w2])
-                gi.append(a), gw2.append(b), gb2.append(c)
-            mark("conv2 library part")
-        if native_w2:   # hand-written fp32-MFMA weight gradient on dy2 in accumulator order; bias gradient == 0
-            gw2 = enc.conv2_wgrad(p1, B, Fr)
-            gb2 = torch.zeros(ns, 64, device=logmel.device)
-            mark("conv2_wgrad")
-        else:
-            gw2, gb2 = torch.stack(gw2), torch.stack(gb2)
-        if native_d2:   # hand-written input gradient (chunked fp32-MFMA conv on dy2, Dropout mask fused)
-            dp1 = enc.conv2_dgrad(dy2, B, Fr, mask, ctx.drop_p)
-            mark("conv2_dgrad")
-        else:
-            dp1 = torch.stack(gi, 1)
-            if mask is not None:
-                dp1 = dp1 * (mask.to(dp1.dtype) * (1.0 / (1.0 - ctx.drop_p)))
-            mark("stack+mask")
-        if _CONV1_WGRAD_MIOPEN and not getattr(enc, "train_f16", False):   # MST_CONV1_WGRAD=miopen: library weight gradient on an NCHW dy (A/B checks)
-            dy1, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, sync=sync)
-            mark("apply_bwd1")
-            gw1, gb1 = [], []
-            for i in range(ns):
-                _, b, c = bw(dy1[i], logmel[:, :, i * ov:i * ov + sp, :].contiguous(), c1w[i], [32], [1, 1], [3, 3],
-                             [1, 1], False, [0, 0], 1, [False, True, True])
-                gw1.append(b), gb1.append(c)
-            gw1, gb1 = torch.stack(gw1), torch.stack(gb1)
-        else:                     # hand-written fp32-MFMA weight gradient on dy in accumulator order
-            _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
-            mark("apply_bwd1")
-            gw1 = enc.conv1_wgrad(logmel, B, Fr)
-            gb1 = torch.zeros(ns, 32, device=logmel.device)   # exactly 0 in front of a batch-statistics BatchNorm
+        gw2 = enc.conv2_wgrad(p1, B, Fr)          # weight gradient on dy2 in accumulator order
+        gb2 = torch.zeros(ns, 64, device=logmel.device)   # exactly 0 in front of a batch-statistics BatchNorm
+        mark("conv2_wgrad")
+        dp1 = enc.conv2_dgrad(dy2, B, Fr, mask, ctx.drop_p)   # input gradient (Dropout mask fused)
+        mark("conv2_dgrad")
+        _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
+        mark("apply_bwd1")
+        gw1 = enc.conv1_wgrad(logmel, B, Fr)
+        gb1 = torch.zeros(ns, 32, device=logmel.device)
         mark("conv1_wgrad")
         if _TRAIN_TIMING:
             torch.cuda.synchronize()
@@ -683,6 +669,8 @@ class MixingStyleEncoder(nn.Module):
 
     def forward_from_logmel(self, logmel, mixing_features):
         auto = self._needs_autograd(mixing_features)
+        if isinstance(logmel, LogMel) and not (self.encoder_backend == "hip" and not auto and not self.training):
+            logmel = logmel.to_reference()   # only the eval forward in libmst.so reads the channel-minor layouts
         if self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict"):
             why = self._hip_trunk_refusal(logmel)
             if why is None:
@@ -713,11 +701,18 @@ class MixingStyleEncoder(nn.Module):
         hold real values are used as given."""
         bins = detailed_bins_for_feature_dim(self.film_encoder.feature_dim)
         pre = self.audio_encoder.mel_preprocessor
+        has_feats = bins is not None and (bins == 0 or bins <= self.audio_encoder.n_mels)
+        plan = pre.plan(bins if has_feats else 0)
+        # the eval forward in libmst.so takes the log-mel in its internal channel-minor layout when stage A can write it
+        # (whole-line stores there, 256-byte runs / ready-made float16 operands for conv1); every other path -- training,
+        # the PyTorch backend -- gets the reference's (B, 8, n_mels, frames) tensor
+        layout = _lib.LOGMEL_REF
+        if self.encoder_backend == "hip" and not self.training and not self._needs_autograd(mixing_features):
+            want = self.hip_encoder().preferred_layout()
+            if plan.supports_layout(want):
+                layout = want
         with torch.no_grad():
-            if bins is not None and (bins == 0 or bins <= self.audio_encoder.n_mels):
-                logmel, feats = pre.plan(bins).forward_stems(stems_dict, True, True)
-            else:   # no feature layout of this size exists: the caller must bring real features
-                logmel, feats = pre(stems_dict), None
+            logmel, feats = plan.forward_stems(stems_dict, True, has_feats, layout, want_absmax=layout == _lib.LOGMEL_CM16)
         mf = mixing_features.to(logmel.device)
         if feats is not None:
             mf = torch.where(is_deferred(mf), feats.to(mf.dtype), mf)

@@ -45,8 +45,12 @@ def test_augment_stems_vs_golden_and_oracle(seed):
     # decisions: the RNG consumption is bit-identical to the reference's
     assert np.array_equal(np.array(draws, dtype=np.float64), g[f"seed{seed}.rand_draws"])
     assert int(g[f"seed{seed}.reverb"]) == int("reverb_ir" in aug.last_trace)
-    if "reverb_ir" in aug.last_trace:
-        assert abs(float(aug.last_trace["reverb_ir"].double().sum()) - 0) >= 0  # drawn on the host
+    if "reverb_ir" in aug.last_trace:   # the impulse response is the reference's draw, bit for bit (src/mixing_utils.py:460-464)
+        r = aug.last_trace["reverb_randn"]
+        assert np.array_equal(r[:8].numpy(), g[f"seed{seed}.ir_randn_head"])
+        assert float(r.double().sum()) == float(g[f"seed{seed}.ir_randn_sum"])
+        t = torch.linspace(0, 0.5, 22050)
+        assert torch.equal(aug.last_trace["reverb_ir"], torch.exp(-t / 0.125) * r * 0.1)
     y8 = omel.stems_dict_to_tensor({k: v.cpu() for k, v in y.items()})
     idx = torch.from_numpy(g[f"seed{seed}.idx"])
     close(y8.flatten()[idx], g[f"seed{seed}.samples"])

@@ -37,6 +37,23 @@ def close(a, ref, tol=1e-4, name=None):
     np.testing.assert_allclose(a, ref, rtol=tol, atol=tol * scale)
 
 
+def close_elementwise(a, ref, tol=1e-4, floor_frac=1e-2, max_miss=0, hard=None, name=None):
+    """ELEMENT-wise bar (north_star: embeddings within 1e-4 rel): |d| <= tol * max(|ref|, floor_frac * max|ref|) for every
+    element (the floor keeps elements that are ~0 next to O(1) neighbours -- ReLU outputs -- from dividing by nothing; it is
+    the floor tests/parity.py reports with).  max_miss elements may exceed it, none by more than `hard`; the count is
+    printed into the parity report either way."""
+    import inspect
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    fr = inspect.stack()[1]
+    row = parity.record((name or f"{fr.function}:{fr.lineno}") + " [element-wise]", a, ref, floor_frac=floor_frac)
+    rel = np.abs(a - ref) / np.maximum(np.abs(ref), floor_frac * np.abs(ref).max())
+    miss = int((rel > tol).sum())
+    assert miss <= max_miss, f"{miss} of {rel.size} elements beyond {tol:g} (max {rel.max():.2e}); allowed {max_miss}"
+    if hard is not None:
+        assert rel.max() <= hard, f"worst element {rel.max():.2e} > {hard:g}"
+    return row
+
+
 def close_f16(a, ref, tol=1e-4, frac=5e-4, hard=5e-3, name=None):
     """Comparison of tensors that sit behind a STORED float16 value (the f16 training mode keeps its raw convolution outputs
     as float16): where the kernel's fp32 accumulation order and the oracle's differ in the last bit, a stored value lands on
@@ -77,6 +94,7 @@ def test_encoder_vs_golden_and_oracle(tag, cfg, T):
     close(pin.flatten()[torch.from_numpy(g[f"{tag}.pool_in_idx"])], g[f"{tag}.pool_in_samples"])
     close(pin.double().sum(-1), g[f"{tag}.pool_in_rowsum"])
     close(emb.cpu(), g[f"{tag}.embedding"])
+    close_elementwise(emb.cpu(), g[f"{tag}.embedding"])   # every element within 1e-4 of the reference's own output
     # full tensors against the oracle on the same log-mel
     otaps = {}
     oemb = oenc.encoder_from_logmel(sd, lm.cpu(), feats, cfg["split_size"], cfg["overlap"], otaps)
@@ -84,6 +102,7 @@ def test_encoder_vs_golden_and_oracle(tag, cfg, T):
         close(p1[:, i], otaps[f"pool1_{i}"])
     close(pin, otaps["pool_in"])
     close(emb.cpu(), oemb)
+    close_elementwise(emb.cpu(), oemb)
 
 
 def test_module_forward_matches_reference_call_contract():
@@ -838,6 +857,37 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgnam
         if walks == 1:
             with pytest.raises(RuntimeError, match="second backward"):
                 o1.backward()
+    # ... and with DIFFERENT parameters in the passes that are alive together: forward A (P0), forward B (P1), backward A (the
+    # fragments go back to P0), forward C (P2), backward B -- B's convolution input gradient and BatchNorm backward must run
+    # on P1 (a pass counter that is written back by a backward would mistake C's fragments for B's)
+    for prec in ("fp32", "f16x3"):
+        model.train_precision = prec
+        trunk = [q for c in model.audio_encoder.subnet_cnns for q in (c.conv2.weight, c.bn1.weight)]
+        P0 = [q.detach().clone() for q in trunk]
+
+        def put(k):   # trunk parameters only: their values reach the graph through torch.stack copies, nothing saved is modified
+            with torch.no_grad():
+                for q, q0 in zip(trunk, P0):
+                    q.copy_(q0 * (1.0 + 0.07 * k) + 0.013 * k * (q0.dim() == 1))
+        put(1)
+        model.zero_grad()
+        (model(stems, feats) * R).sum().backward()
+        gB = {n: q.grad.clone() for n, q in model.named_parameters()}
+        put(0)
+        oA = (model(stems, feats) * R).sum()
+        put(1)
+        oB = (model(stems, feats) * R).sum()
+        oA.backward()
+        put(2)
+        oC = (model(stems, feats) * R).sum()   # noqa: F841  (alive, never walked)
+        model.zero_grad()
+        oB.backward()
+        for n, q in model.named_parameters():
+            den = gB[n].abs().max().item()
+            if den > 1e-9:
+                assert (q.grad - gB[n]).abs().max().item() <= 1e-5 * den, (prec, n)
+        put(0)
+        del oC
     model.train_precision = "fp32"
     # dropout after the first pooling: every element is either dropped or scaled by 1 / (1 - p)
     enc = model._hip_train
@@ -896,6 +946,10 @@ def test_song_a_real_music_end_to_end():
         model.conv1_precision = "fp32"
     close(emb.cpu(), g["embedding"], 2e-4)
     close(emb16.cpu(), g["embedding"], 2e-4)
+    # element-wise on real music: the log-mel of low-passed stems carries fp32 FFT noise in its quiet bins (check_logmel), which
+    # a handful of embedding elements inherit -- counted and bounded here (measured: 20 of 1536 beyond 1e-4, worst 2.9e-4)
+    close_elementwise(emb.cpu(), g["embedding"], max_miss=48, hard=5e-4, name="song_A embedding fp32 kernels vs reference")
+    close_elementwise(emb16.cpu(), g["embedding"], max_miss=48, hard=5e-4, name="song_A embedding f16x3-all vs reference")
 
 
 def test_retrieval_validation_on_hip_path(tmp_path):

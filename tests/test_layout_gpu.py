@@ -1,0 +1,154 @@
+"""GPU parity of the encoder-internal CHANNEL-MINOR log-mel layouts (include/mst.h MST_LOGMEL_CM32 / CM16).
+
+Stage A writes the same log-mel VALUES whatever the layout (the arithmetic up to the store is shared), and conv1 stages the
+same LDS patch from either, so every comparison here is BIT-EXACT:
+  * CM32 == the reference-layout tensor, permuted; CM16 hi / lo == the float16 split the f16 conv1 kernel used to derive
+    itself (hi = f16(x), lo = f16(x - hi)); absmax == max |log-mel| per clip;
+  * the eval encoder gives identical embeddings / taps from a channel-minor log-mel and from the reference layout, in
+    every precision mode -- so all the golden / oracle parity tests of test_encoder_gpu.py carry over unchanged;
+  * the module's forward (which negotiates the layout) equals the explicit reference-layout pipeline.
+The reference computes this tensor at src/model.py:41-67 (layout (B, 8, n_mels, frames)).
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import mel as omel
+
+pytestmark = pytest.mark.gpu
+
+
+def _plan(n_fft=1024, hop=256, n_mels=128, bins=0):
+    from mst_amd.mixing_utils import MelFeatPlan
+    return MelFeatPlan(44100, n_fft, hop, n_mels, bins)
+
+
+def _stems(B, T, seed=0):
+    x = torch.stack([cases.synth_clip(seed + c, T) for c in range(B)], 0)
+    return omel.tensor_to_stems_dict(x.cuda())
+
+
+CASES = [
+    ("default_10s", dict(n_fft=1024, hop=256, n_mels=128), 3, 441000),
+    ("default_ragged", dict(n_fft=1024, hop=256, n_mels=128), 2, 44100 + 77),     # odd length, ragged last block
+    ("default_tiny", dict(n_fft=1024, hop=256, n_mels=128), 1, 1300),              # fewer frames than one block per wave
+    ("mels80", dict(n_fft=1024, hop=256, n_mels=80), 2, 66150),                    # bands past n_mels masked in the stores
+    ("mels256", dict(n_fft=1024, hop=256, n_mels=256), 2, 66150),                  # 4 bands per lane (BASELINE configs[4])
+    ("launcher_2048", dict(n_fft=2048, hop=512, n_mels=80), 2, 441000),            # scripts/train_baseline.sh shapes
+]
+
+
+@pytest.mark.parametrize("tag,cfg,B,T", CASES, ids=[c[0] for c in CASES])
+def test_stage_a_channel_minor_layouts_hold_the_reference_values_bit_for_bit(tag, cfg, B, T):
+    from mst_amd import _lib
+    plan = _plan(**cfg)
+    assert plan.supports_layout(_lib.LOGMEL_CM32) and plan.supports_layout(_lib.LOGMEL_CM16)
+    d = _stems(B, T)
+    ref, f_ref = plan.forward_stems(d, True, True)
+    cm32, f32 = plan.forward_stems(d, True, True, _lib.LOGMEL_CM32, want_absmax=True)
+    cm16, f16 = plan.forward_stems(d, True, True, _lib.LOGMEL_CM16, want_absmax=True)
+    torch.cuda.synchronize()
+    F = plan.frames(T)
+    assert tuple(cm32.data.shape) == (B, F, cfg["n_mels"], 8) and cm32.data.dtype == torch.float32
+    assert tuple(cm16.data.shape) == (B, F, cfg["n_mels"], 8) and cm16.data.dtype == torch.float16 and cm16.lo.dtype == torch.float16
+    want = ref.permute(0, 3, 2, 1).contiguous()
+    assert torch.equal(cm32.data, want), "CM32 must be a pure re-layout"
+    hi = want.half()
+    lo = (want - hi.float()).half()
+    assert torch.equal(cm16.data, hi) and torch.equal(cm16.lo, lo), "CM16 = (f16(x), f16(x - f16(x)))"
+    amax = ref.abs().amax(dim=(1, 2, 3))
+    for lm in (cm32, cm16):
+        assert torch.equal(lm.absmax.view(torch.float32), amax), "absmax = max |log-mel| per clip (float bits)"
+    assert torch.equal(f32, f_ref) and torch.equal(f16, f_ref), "the features do not depend on the log-mel layout"
+    assert torch.equal(cm32.to_reference(), ref)
+
+
+def test_channel_minor_needs_the_sliding_window_kernels_and_says_so():
+    from mst_amd import _lib
+    plan = _plan(n_fft=512, hop=128, n_mels=64)   # served by the generic stage-A kernel
+    assert not plan.supports_layout(_lib.LOGMEL_CM32)
+    with pytest.raises(_lib.MstError, match="layout"):
+        plan.forward_stems(_stems(1, 22050), True, False, _lib.LOGMEL_CM32)
+
+
+def _build(cfg, precision="fp32"):
+    from mst_amd.model import MixingStyleEncoder
+    m = MixingStyleEncoder(channels=8, feature_dim=64, **cfg)
+    sd = cases.make_state_dict(cfg, seed=42)
+    full = dict(m.state_dict())
+    full.update(sd)
+    m.load_state_dict(full, strict=True)
+    m.conv1_precision = precision
+    return m.cuda().eval()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3", "f16x3-all", "f16"])
+@pytest.mark.parametrize("cfgname,T,B", [("default", 66150 + 13, 3), ("baseline_sh", 66150, 2)])
+def test_encoder_is_bit_identical_from_either_layout(cfgname, T, B, precision):
+    from mst_amd import _lib
+    cfg = cases.CFG_DEFAULT if cfgname == "default" else cases.CFG_BASELINE_SH
+    m = _build(cfg, precision)
+    enc = m.hip_encoder()
+    lay = enc.preferred_layout()
+    assert lay == (_lib.LOGMEL_CM32 if precision == "fp32" else _lib.LOGMEL_CM16)
+    plan = m.audio_encoder.mel_preprocessor.plan(0)
+    d = _stems(B, T, seed=3)
+    ref, feats = plan.forward_stems(d, True, True)
+    cm, _ = plan.forward_stems(d, True, True, lay, want_absmax=True)
+    with torch.no_grad():
+        e0, t0 = enc.forward(ref, feats, taps=True)
+        e1, t1 = enc.forward(cm, feats, taps=True)
+    torch.cuda.synchronize()
+    for k in ("film", "pool1", "pool_in"):
+        assert torch.equal(t0[k], t1[k]), k
+    assert torch.equal(e0, e1)
+    # the module's own forward negotiates the layout and fills the deferred features from the same launch
+    from mst_amd.mixing_utils import deferred_features
+    with torch.no_grad():
+        e2 = m(d, torch.stack([deferred_features(64)] * B).cuda())
+    assert torch.equal(e2, e0)
+
+
+def test_config5_geometry_from_channel_minor():
+    """256 mels / 24 sub-bands (BASELINE configs[4] shapes), 4 bands per lane in stage A."""
+    from mst_amd import _lib
+    cfg = dict(sample_rate=44100, n_fft=1024, hop_length=256, n_mels=256, split_size=20, overlap=10, embed_dim=768)
+    m = _build(cfg)
+    plan = m.audio_encoder.mel_preprocessor.plan(0)
+    d = _stems(1, 88200, seed=5)
+    ref, feats = plan.forward_stems(d, True, True)
+    cm, _ = plan.forward_stems(d, True, True, _lib.LOGMEL_CM32)
+    with torch.no_grad():
+        e0 = m.hip_encoder().forward(ref, feats)
+        e1 = m.hip_encoder().forward(cm, feats)
+    assert torch.equal(e0, e1)
+
+
+def test_layout_that_does_not_fit_the_precision_mode_is_refused():
+    from mst_amd import _lib
+    m = _build(cases.CFG_DEFAULT, "fp32")
+    plan = m.audio_encoder.mel_preprocessor.plan(0)
+    d = _stems(1, 44100)
+    cm16, feats = plan.forward_stems(d, True, True, _lib.LOGMEL_CM16, want_absmax=True)
+    with pytest.raises(_lib.MstError, match="layout"):
+        m.hip_encoder().forward(cm16, feats)
+
+
+def test_full_size_batch_properties_channel_minor():
+    """BASELINE size (72 clips of 10 s would be 0.5 GB of log-mel twice; 24 clips here): size-independent properties of the
+    channel-minor path -- batch independence (a clip's values do not depend on its neighbours) and equality with the
+    reference layout on a strided sample of frames."""
+    from mst_amd import _lib
+    plan = _plan()
+    B, T = 24, 441000
+    x = torch.stack([cases.synth_clip(c % 5, T) for c in range(B)], 0).cuda()
+    d = omel.tensor_to_stems_dict(x)
+    cm, _ = plan.forward_stems(d, True, False, _lib.LOGMEL_CM32)
+    one, _ = plan.forward_stems(omel.tensor_to_stems_dict(x[7:8]), True, False, _lib.LOGMEL_CM32)
+    assert torch.equal(cm.data[7], one.data[0])
+    assert torch.equal(cm.data[2], cm.data[7])   # clips 2 and 7 are the same synthetic clip
+    ref, _ = plan.forward_stems(omel.tensor_to_stems_dict(x[:2]), True, False)
+    fr = torch.arange(0, plan.frames(T), 97, device="cuda")
+    assert torch.equal(cm.data[:2].index_select(1, fr), ref.permute(0, 3, 2, 1).index_select(1, fr))
+    assert np.isfinite(cm.data.float().sum().item())

@@ -92,8 +92,17 @@ def check_logmel(lm, ref, tol=1e-4, x=None, cfg=None, name="log-mel"):
     if live.any():
         zg = (g64[live] / unit[live]).pow(2).mean().sqrt().item()
         zr = (r64[live] / unit[live]).pow(2).mean().sqrt().item()
+    # the literal 1e-4 bar as plain counts (GPU test log): which share of the bins is further than tol * max(1, |ref|) from the
+    # FLOAT64 log-mel for the kernel and for the reference's own fp32 arithmetic (torch.stft / pocketfft), and from each other
+    frac_g64 = float((g64 > tol * den).double().mean())
+    frac_r64 = float((r64 > tol * den).double().mean())
+    frac_g32 = float((g32 > tol * den).double().mean())
     parity.note(name + " FFT noise (units of 2^-24 |frame|)", gpu_max=zg_max, oracle32_max=zr_max, gpu_rms=zg,
                 oracle32_rms=zr, well_conditioned_frac=float(well.double().mean()))
+    parity.note(name + " share of bins beyond 1e-4", gpu_vs_float64=frac_g64, fp32_oracle_vs_float64=frac_r64,
+                gpu_vs_fp32_oracle=frac_g32, bins=int(den.numel()))
+    assert frac_g64 <= 1.25 * frac_r64 + 1e-3, \
+        f"share of log-mel bins beyond {tol:g} of the float64 result: gpu {frac_g64:.4f}, the reference's fp32 arithmetic {frac_r64:.4f}"
     assert zg_max <= 2.0 * max(zr_max, 8.0), \
         f"log-mel worst-bin noise: gpu needs {zg_max:.1f} units, the fp32 oracle {zr_max:.1f}"
     assert zg <= 2.0 * zr + 1.0, f"rms noise (units): gpu {zg:.2f} vs fp32 oracle {zr:.2f}"

@@ -28,9 +28,9 @@ def _count_stage_a(monkeypatch):
     calls = []
     real = MelFeatPlan.forward_stems
 
-    def counted(self, stems_dict, want_logmel=True, want_feats=True):
+    def counted(self, stems_dict, want_logmel=True, want_feats=True, *a, **k):
         calls.append((want_logmel, want_feats, next(iter(stems_dict.values())).shape[0]))
-        return real(self, stems_dict, want_logmel, want_feats)
+        return real(self, stems_dict, want_logmel, want_feats, *a, **k)
     monkeypatch.setattr(MelFeatPlan, "forward_stems", counted)
     return calls
 
