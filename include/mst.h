@@ -213,14 +213,16 @@ typedef struct mst_encoder_train_taps {
    * forward runs in three calls with the same arguments -- 1: FiLM + conv1 raw output and its statistics; 2: BatchNorm 1 +
    * FiLM + pooling + conv2 raw output and its statistics; 3: BatchNorm 2 + FiLM + pooling + head -- and between the calls
    * the caller SUMS the statistics accumulators over its ranks (mst_encoder_train_stats_buffer: 64-bit integers, so the sum
-   * is exact and order-independent).  count_scale: ranks that contribute (the accumulators then hold count_scale * B clips);
-   * 0 = 1.                                                                                                              */
+   * is exact and order-independent).  The buffer's last word pair carries the CLIP COUNT: every phased call writes this
+   * rank's B there, the all-reduce turns it into the global count, and the BatchNorm kernels divide by it -- ranks may hold
+   * different numbers of clips (a ragged last batch).  count_scale: kept for ABI compatibility, ignored by the phased calls
+   * (phase 0 normalises by B).                                                                                            */
   int phase;
   double count_scale;
 } mst_encoder_train_taps;
 size_t mst_encoder_train_workspace_bytes(const mst_encoder* enc, int B, int frames);
 /* Where the statistics accumulators of conv layer 1 or 2 sit inside the training workspace: byte offset and number of
- * int64 words ([n_sub][C][2 sums][2 words]).  The forward (sum y, sum y^2) and the backward pass (sum dz, sum dz * zhat)
+ * int64 words ([n_sub][C][2 sums][2 words], then 2 words whose first is the rank's clip count -- sum them all).  The forward (sum y, sum y^2) and the backward pass (sum dz, sum dz * zhat)
  * use the same words; all-reduce them with SUM between the phases.  Returns 0 on success.                          */
 int mst_encoder_train_stats_buffer(const mst_encoder* enc, int layer, int B, int frames, size_t* offset_bytes,
                                    size_t* n_int64);

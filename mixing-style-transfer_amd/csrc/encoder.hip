@@ -1680,13 +1680,19 @@ struct FoldParams {
   double count;            // positions per (band, channel): B * rows * cols
   float eps;
   int nsub, cout, goff, boff;   // FiLM gamma / beta offsets inside a band's 192 values
+  // cross-rank statistics (phased calls): the clip count comes from the device word that was summed over the ranks together
+  // with the statistics (the word after stats[nsub][COUT][2]), times per_clip = rows * cols -- ranks may hold DIFFERENT
+  // numbers of clips (ragged last batch) and still agree on mean / variance bit for bit.  NULL: `count` from the host.
+  const long long* clips;
+  double per_clip;
 };
 
 __global__ void bn_fold_kernel(const FoldParams p) {   // grid (nsub, B), block COUT
   const int band = blockIdx.x, b = blockIdx.y, ch = threadIdx.x;
   const size_t i = (size_t)band * p.cout + ch;
-  const double mean = mst::det_get(p.stats[i * 2]) / p.count;
-  const double var = fmax(mst::det_get(p.stats[i * 2 + 1]) / p.count - mean * mean, 0.0);
+  const double count = p.clips ? (double)p.clips[0] * p.per_clip : p.count;
+  const double mean = mst::det_get(p.stats[i * 2]) / count;
+  const double var = fmax(mst::det_get(p.stats[i * 2 + 1]) / count - mean * mean, 0.0);
   const double invstd = 1.0 / sqrt(var + (double)p.eps);
   if (b == 0) p.bnstat[i] = make_float2((float)mean, (float)invstd);
   const float* fl = p.film + ((size_t)b * p.nsub + band) * 192;
@@ -1826,7 +1832,15 @@ struct ApplyBwdParams {
   int B, nsub, tiles_r, tiles_c, rows, cols, goff, boff;
   double count;
   int chunks;              // pass A: blocks per (clip, band)
+  const long long* clips;  // cross-rank statistics: see FoldParams::clips (count = clips[0] * rows * cols)
 };
+__device__ __forceinline__ double bwd_count(const ApplyBwdParams& p) {
+  return p.clips ? (double)p.clips[0] * (double)p.rows * (double)p.cols : p.count;
+}
+__global__ void set_clips_kernel(long long* a, long long* b, long long clips) {
+  if (a) a[0] = clips, a[1] = 0;
+  if (b) b[0] = clips, b[1] = 0;
+}
 
 template <int LAYER, int SUB>
 __device__ __forceinline__ void unit_geometry(int tr, int tc, int g, int e, int& row, int& col) {
@@ -1960,8 +1974,9 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
   const float2 ms = p.bnstat[band * C::COUT + ch];
   const float gb = p.bn_w[band * C::COUT + ch];
   const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
-  const double m1 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2]) / p.count,
-               m2 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2 + 1]) / p.count;
+  const double cnt = bwd_count(p);
+  const double m1 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2]) / cnt,
+               m2 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2 + 1]) / cnt;
   const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (size_t)u * NV);
   float v[NV], df[NV];
 #pragma unroll
@@ -2976,8 +2991,8 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
   const size_t ybytes = e->train_f16 == 1 ? 2 : 4;   // mode 1 stores the raw conv outputs as float16
   T.y1 = take((size_t)B * ns * T.tr1 * T.tc1 * 2 * 64 * 20 * ybytes);
   T.y2 = take((size_t)B * ns * T.tr2 * T.tc2 * 4 * 64 * 16 * ybytes);
-  T.stats1 = take((size_t)ns * 32 * 2 * sizeof(mst::DetAcc));
-  T.stats2 = take((size_t)ns * 64 * 2 * sizeof(mst::DetAcc));
+  T.stats1 = take((size_t)(ns * 32 * 2 + 1) * sizeof(mst::DetAcc));   // + the clip-count word that rides with the sums
+  T.stats2 = take((size_t)(ns * 64 * 2 + 1) * sizeof(mst::DetAcc));
   T.bn1 = take((size_t)ns * 32 * 8);
   T.bn2 = take((size_t)ns * 64 * 8);
   T.dfilm_acc = take((size_t)B * ns * 192 * sizeof(mst::DetAcc));
@@ -3009,7 +3024,9 @@ int mst_encoder_train_stats_buffer(const mst_encoder* e, int layer, int B, int f
               "mst_encoder_train_stats_buffer: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   *offset_bytes = layer == 1 ? T.stats1 : T.stats2;
-  *n_int64 = (size_t)e->cfg.n_subbands * (layer == 1 ? 32 : 64) * 2 * (sizeof(mst::DetAcc) / 8);
+  // [n_sub][C][2 sums][2 words] + one more pair whose first word is this rank's clip count: summed with the rest, it gives
+  // every rank the global count, so ranks with different numbers of clips (a ragged last batch) normalise identically
+  *n_int64 = ((size_t)e->cfg.n_subbands * (layer == 1 ? 32 : 64) * 2 + 1) * (sizeof(mst::DetAcc) / 8);
   return MST_OK;
 }
 
@@ -3054,6 +3071,9 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   if (run_a) {
   MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * sizeof(mst::DetAcc), st));
   MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * sizeof(mst::DetAcc), st));
+  if (phase != 0)   // cross-rank statistics: this rank's clip count rides with each layer's sums
+    hipLaunchKernelGGL(set_clips_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<long long*>(stats1 + ns * 32 * 2),
+                       reinterpret_cast<long long*>(stats2 + ns * 64 * 2), (long long)B);
   if (taps && taps->film_in) {   // FiLM parameters computed by the caller (its MLP keeps its autograd graph)
     MST_HIP_CHECK(hipMemcpyAsync(film, taps->film_in, (size_t)B * ns * 192 * 4, hipMemcpyDeviceToDevice, st));
   } else {   // FiLM MLP (its eval-mode affines are overwritten by bn_fold_kernel below)
@@ -3131,7 +3151,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   {
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn1);
     FoldParams fp{stats1, e->bn1w, e->bn1b, film, aff1, bnstat, cscale * B * e->cfg.split_size * frames, e->cfg.bn_eps,
-                  ns, 32, 0, 32};
+                  ns, 32, 0, 32, phase ? reinterpret_cast<const long long*>(stats1 + ns * 32 * 2) : nullptr,
+                  (double)e->cfg.split_size * frames};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(32), 0, st, fp);
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
                    B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr, frames};
@@ -3230,7 +3251,8 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
   if (run_c) {
   {
     float2* bnstat = reinterpret_cast<float2*>(ws + T.bn2);
-    FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, cscale * B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128};
+    FoldParams fp{stats2, e->bn2w, e->bn2b, film, aff2, bnstat, cscale * B * e->H1 * L.W1, e->cfg.bn_eps, ns, 64, 64, 128,
+                  phase ? reinterpret_cast<const long long*>(stats2 + ns * 64 * 2) : nullptr, (double)e->H1 * L.W1};
     hipLaunchKernelGGL(bn_fold_kernel, dim3(ns, B), dim3(64), 0, st, fp);
     ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64,
                    nullptr, nullptr, L.W1};
@@ -3299,7 +3321,11 @@ int mst_encoder_train_backward_apply_phase(const mst_encoder* e, int layer, int 
   if (run_2) {
     MST_HIP_CHECK(hipMemsetAsync(sums, 0, (size_t)ns * cout * 2 * sizeof(mst::DetAcc), st));
     MST_HIP_CHECK(hipMemsetAsync(p.dfilm_acc, 0, (size_t)B * ns * 192 * sizeof(mst::DetAcc), st));
+    if (phase != 0)
+      hipLaunchKernelGGL(set_clips_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<long long*>(sums + ns * cout * 2),
+                         static_cast<long long*>(nullptr), (long long)B);
   }
+  if (phase != 0) p.clips = reinterpret_cast<const long long*>(sums + ns * cout * 2);
   // f16 training: the backward pass runs under an internal power-of-two loss scale s chosen from max |d pool_in| (layer 2 =
   // the start of the trunk's backward); d pool1 carries it to layer 1; every result that leaves the trunk is divided by s.
   // In this mode `dy` of layer 2 is the f16 channel-minor operand of the f16 dgrad kernel, [n_sub][B][H1][W1][64] halves.

@@ -635,9 +635,12 @@ class MixingStyleEncoder(nn.Module):
                                             st(lambda c: c.conv2.weight), st(lambda c: c.conv2.bias),
                                             st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias), float(p), sync)
         with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
-            B, Fr = logmel.shape[0] * (sync.world if sync is not None else 1), logmel.shape[-1]
-            for stat, name, n in ((bn1, "bn1", B * ae.split_size * Fr), (bn2, "bn2", B * (ae.split_size // enc.sub) * (Fr // 5))):
-                mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * (n / max(n - 1, 1))
+            B, Fr = logmel.shape[0], logmel.shape[-1]
+            if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different
+                B = enc.stats_view(1, B, Fr)[-2].to(torch.float64)   # numbers of clips); a device scalar: no host sync
+            for stat, name, n in ((bn1, "bn1", B * (ae.split_size * Fr)), (bn2, "bn2", B * ((ae.split_size // enc.sub) * (Fr // 5)))):
+                corr = (n / torch.clamp(n - 1, min=1)).float() if torch.is_tensor(n) else n / max(n - 1, 1)
+                mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * corr
                 bns = [getattr(c, name) for c in cn]
                 moms = {bn.momentum if bn.momentum is not None else 0.1 for bn in bns}
                 if len(moms) == 1:   # one multi-tensor launch per update instead of 3 x n_sub tiny kernels
@@ -679,6 +682,8 @@ class MixingStyleEncoder(nn.Module):
                    f"on PyTorch-ROCm/MIOpen autograd instead (about 2x the step time, library numerics)")
             if self.train_backend == "hip-strict":
                 raise RuntimeError(msg)
+            if self.sync_bn:   # the decision is per rank: a rank that fell back would skip the statistics all-reduces its peers
+                raise RuntimeError(msg + " -- refused with sync_bn: the other ranks would wait in their collectives forever")
             if why not in self._warned:
                 self._warned.add(why)
                 warnings.warn(msg, RuntimeWarning, stacklevel=2)

@@ -124,6 +124,12 @@ def make_state_dict(cfg, seed=42, feature_dim=64):
     return sd
 
 
+def sample_idx(n, k=2048, seed=0):
+    """Deterministic sample of k of n flat indices (the goldens store the values only, not the indices)."""
+    import numpy as np
+    return np.random.default_rng(seed).choice(n, size=min(k, n), replace=False).astype(np.int64)
+
+
 def checksum(x: torch.Tensor):
     x = x.double()
     return [float(x.sum()), float((x * x).sum())]

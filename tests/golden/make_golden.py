@@ -326,8 +326,86 @@ def gen_dataset():
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
 
 
+CFG_C5 = dict(sample_rate=44100, n_fft=1024, hop_length=256, n_mels=256, split_size=20, overlap=10, embed_dim=768)   # BASELINE configs[4] shapes
+
+
+def gen_train():
+    """The reference's own TRAINING arithmetic (src/train.py:246-262,292-296 on src/model.py in train mode): MixingStyleEncoder.train()
+    -- BatchNorm with batch statistics (model.py:118,125), every nn.Dropout.p = 0 (dropout masks are not reproducible across
+    implementations) -- followed by (a) InfoNCELoss(0.1) on labels [0, 0, 1, 1] and loss.backward(), the reference's step, and
+    (b) the projection loss (embeddings * R).sum() with a fixed random R, which exercises every gradient path at O(1) magnitude
+    (random-init embeddings of different clips are nearly parallel, so InfoNCE's gradient is small).  Stored per case: losses,
+    train-mode embeddings, the batch statistics that bn1 / bn2 of three sub-bands saw, the running statistics after the step,
+    and of EVERY parameter gradient 512 sampled entries (cases.sample_idx(numel, 512, 1000 + j), not stored) + its L2 norm, max
+    and sum -- from the reference modules in fp32 and once more in float64 (the yardstick: two fp32 evaluations of a gradient
+    differ by their own rounding)."""
+    out = {}
+    for tag, cfg, B, T in (("default", cases.CFG_DEFAULT, 4, 66150), ("c5", CFG_C5, 4, 66150)):
+        x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
+        fe = ref_mu.MixingFeatureExtractor(cfg["sample_rate"], cfg["n_fft"], cfg["hop_length"], cfg["n_mels"])
+        feats = torch.stack([fe.extract_all_features(stems_dict(x[b])) for b in range(B)], 0)
+        labels = torch.arange(B) // 2
+        R = torch.randn(B, cfg["embed_dim"], generator=torch.Generator().manual_seed(77))
+        out[f"{tag}.in_checksum"] = np.array(cases.checksum(x))
+        out[f"{tag}.features"] = feats.numpy()
+        out[f"{tag}.labels"] = labels.numpy()
+        out[f"{tag}.R_checksum"] = np.array(cases.checksum(R))
+        for prec, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            for lossname in ("infonce", "proj"):
+                torch.manual_seed(0)
+                m = ref_model.MixingStyleEncoder(channels=8, feature_dim=64, **cfg)
+                sd = cases.make_state_dict(cfg, seed=42)
+                full = dict(m.state_dict())
+                full.update(sd)
+                m.load_state_dict(full, strict=True)
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.Dropout):
+                        mod.p = 0.0
+                m = m.to(dt).train()
+                ns = m.audio_encoder.n_subbands
+                stats, hooks = {}, []
+                for i in (0, ns // 2, ns - 1):
+                    cnn = m.audio_encoder.subnet_cnns[i]
+                    for name, bn in (("bn1", cnn.bn1), ("bn2", cnn.bn2)):
+                        hooks.append(bn.register_forward_hook(
+                            lambda mod, inp, o, k=f"{name}_{i}": stats.__setitem__(k, (inp[0].detach().mean((0, 2, 3)),
+                                                                                         inp[0].detach().var((0, 2, 3), unbiased=False)))))
+                hooks.append(m.audio_encoder.attention_pooling.register_forward_hook(
+                    lambda mod, inp, o: stats.__setitem__("pool_in", inp[0].detach())))
+                emb = m(stems_dict(x.to(dt)), feats.to(dt))                 # train.py:253 / :299
+                if lossname == "infonce":
+                    loss = ref_loss.InfoNCELoss(temperature=0.1)(emb, labels)   # train.py:256 / :302
+                else:
+                    loss = (emb * R.to(dt)).sum()
+                loss.backward()                                              # train.py:292 / :323
+                for h in hooks:
+                    h.remove()
+                out[f"{tag}.{prec}.{lossname}.loss"] = np.array(loss.item())
+                pin = stats.pop("pool_in")
+                if lossname == "infonce":   # the forward is the same for both losses
+                    out[f"{tag}.{prec}.embedding"] = emb.detach().double().numpy()
+                    out[f"{tag}.{prec}.pool_in_samples"] = pin.flatten()[cases.sample_idx(pin.numel(), 4096, 21)].double().numpy()
+                    out[f"{tag}.pool_in_shape"] = np.array(pin.shape)
+                    for k, (mean, var) in stats.items():
+                        out[f"{tag}.{prec}.{k}.batch_mean"] = mean.double().numpy()
+                        out[f"{tag}.{prec}.{k}.batch_var"] = var.double().numpy()
+                    for n, b in m.named_buffers():
+                        if "running" in n:
+                            out[f"{tag}.{prec}.buf.{n}"] = b.double().numpy()
+                names = []
+                for j, (n, q) in enumerate(m.named_parameters()):
+                    g = q.grad.detach().double().flatten()
+                    names.append(n)
+                    gs = g[cases.sample_idx(g.numel(), 512, 1000 + j)].numpy()
+                    out[f"{tag}.{prec}.{lossname}.grad_samples.{n}"] = gs if prec == "f64" else gs.astype(np.float32)
+                    out[f"{tag}.{prec}.{lossname}.grad_norm.{n}"] = np.array([float(g.norm()), float(g.abs().max()), float(g.sum())])
+                out[f"{tag}.param_names"] = np.array(names)
+                print(f"  train[{tag}, {prec}, {lossname}]: loss {loss.item():.6f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "train.npz"), **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fbanks", "features", "logmel", "encoder", "infonce", "augment", "song_a", "dataset"]
+    which = sys.argv[1:] or ["fbanks", "features", "logmel", "encoder", "infonce", "augment", "song_a", "dataset", "train"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -1,7 +1,8 @@
 """GPU: cross-rank BatchNorm statistics (`MixingStyleEncoder.sync_bn`) over a real torch.distributed group.
 Two ranks on the box's single GPU (gloo carries the CUDA tensors here -- RCCL refuses two ranks on one device; the calls are
 the ones RCCL serves on a node: all_reduce SUM on int64, MAX on int32): the summed parameter gradients of the two-rank step
-equal the single-process step on the whole batch, which is what the reference trains (src/train.py:211 on one GPU)."""
+equal the single-process step on the whole batch, which is what the reference trains (src/train.py:211 on one GPU).  The ranks
+hold DIFFERENT numbers of clips (2 and 4).  An RCCL-backed variant runs when at least two GPUs are visible."""
 import copy
 import os
 import sys
@@ -14,15 +15,16 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, precision, ret):
+def _worker(rank, world, port, precision, ret, backend="gloo"):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch.distributed as dist
     import cases
     from oracle import mel as omel
     from test_encoder_gpu import build_model
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         cfg = cases.CFG_DEFAULT
         model, _ = build_model(cfg)
@@ -34,14 +36,15 @@ def _worker(rank, world, port, precision, ret):
         model.train_backend = whole.train_backend = "hip-strict"
         model.train_precision = whole.train_precision = precision
         model.sync_bn = True
-        B, T, h = 6, 44100, 3
+        B, T = 6, 44100
+        cut = [0, 2, B]   # UNEQUAL shards (2 + 4 clips, a ragged last batch): the global clip count rides with the statistics
         x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.1 * c) for c in range(B)], 0).cuda()
         g = torch.Generator().manual_seed(43)
         feats = (torch.randn(B, 64, generator=g) * 2.0).cuda()
         R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
         with torch.no_grad():
             lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
-        sl = slice(rank * h, (rank + 1) * h)
+        sl = slice(cut[rank], cut[rank + 1])
         loss = (model.forward_from_logmel(lm[sl].contiguous(), feats[sl]) * R[sl]).sum()
         loss.backward()
         tot = loss.detach().clone()
@@ -67,9 +70,26 @@ def _worker(rank, world, port, precision, ret):
 
 @pytest.mark.parametrize("precision", ["fp32", "f16"])
 def test_two_rank_step_with_sync_bn_equals_the_single_process_step(precision):
-    port = 32500 + (os.getpid() % 2000) + (7 if precision == "f16" else 0)
+    import socket
+    with socket.socket() as so:   # a free port, as bench.launch_ranks does
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, port, precision, ret), nprocs=2, join=True)
+    assert {"loss", "worst", "stat"} <= set(ret.keys()), f"rank 0 did not report (a worker failed before the comparison): {dict(ret)}"
     tol = 1e-4 if precision == "fp32" else 3e-2   # f16: per-rank range scales move single float16 roundings
     print(f"sync_bn, 2 ranks, {precision}: loss {ret['loss']:.2e}, worst gradient {ret['worst']}, running statistics {ret['stat']:.2e}")
     assert ret["loss"] < (1e-5 if precision == "fp32" else 1e-3) and ret["worst"][0] < tol and ret["stat"] < 1e-4, dict(ret)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has one")
+def test_two_rank_step_with_sync_bn_over_rccl():
+    """The same step with the statistics exchanged by RCCL (backend "nccl"), one GPU per rank."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, port, "fp32", ret, "nccl"), nprocs=2, join=True)
+    assert {"loss", "worst", "stat"} <= set(ret.keys()), dict(ret)
+    assert ret["loss"] < 1e-5 and ret["worst"][0] < 1e-4 and ret["stat"] < 1e-4, dict(ret)
