@@ -124,6 +124,31 @@ def make_state_dict(cfg, seed=42, feature_dim=64):
     return sd
 
 
+def pcm_clip(c: int, T: int) -> torch.Tensor:
+    """(8, T) int16 PCM stems built with INTEGER arithmetic only (torch.randint + shifts / integer sums): bit-identical on
+    every machine, unlike `synth_clip`, whose sin / exp / randn differ in the last bit between CPU generations (1e-7
+    relative -- harmless under the 1e-4 forward tolerances, but enough to flip a max-pool arg-max in a gradient fixture).
+    vocals: noise, silent first fifth; bass: mono moving sum over 64 samples (low-pass); drums: noise under a sawtooth decay of
+    4096 samples; other: independent L / R, R at 45/64.  Value = sample / 32768."""
+    g = _g(7000 + c)
+    n = torch.randint(-2048, 2048, (8, T), generator=g, dtype=torch.int32)
+    v = n[0:2].clone()
+    v[:, :T // 5] = 0
+    cs = torch.cumsum(n[2].to(torch.int64), 0)
+    ma = cs.clone()
+    ma[64:] -= cs[:-64]
+    b = (ma >> 3).to(torch.int32)
+    env = (4096 - (torch.arange(T) % 4096)).to(torch.int32)
+    d = (n[4:6] * env) >> 12
+    o = torch.stack([n[6], (n[7] * 45) >> 6])
+    return torch.cat([v, torch.stack([b, b]), d, o]).clamp(-32768, 32767).to(torch.int16)
+
+
+def pcm_batch(B: int, T: int) -> torch.Tensor:
+    """(B, 8, T) fp32 = pcm_clip / 32768 (exact)."""
+    return torch.stack([pcm_clip(c, T) for c in range(B)], 0).float() / 32768.0
+
+
 def sample_idx(n, k=2048, seed=0):
     """Deterministic sample of k of n flat indices (the goldens store the values only, not the indices)."""
     import numpy as np

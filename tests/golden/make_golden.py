@@ -341,7 +341,7 @@ def gen_train():
     differ by their own rounding)."""
     out = {}
     for tag, cfg, B, T in (("default", cases.CFG_DEFAULT, 4, 66150), ("c5", CFG_C5, 4, 66150)):
-        x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
+        x = cases.pcm_batch(B, T)   # integer-built PCM: bit-identical on the GPU box (see cases.pcm_clip)
         fe = ref_mu.MixingFeatureExtractor(cfg["sample_rate"], cfg["n_fft"], cfg["hop_length"], cfg["n_mels"])
         feats = torch.stack([fe.extract_all_features(stems_dict(x[b])) for b in range(B)], 0)
         labels = torch.arange(B) // 2
@@ -372,7 +372,29 @@ def gen_train():
                                                                                          inp[0].detach().var((0, 2, 3), unbiased=False)))))
                 hooks.append(m.audio_encoder.attention_pooling.register_forward_hook(
                     lambda mod, inp, o: stats.__setitem__("pool_in", inp[0].detach())))
+                gaps = {}
+                if prec == "f64" and lossname == "infonce":
+                    # how close every max-pool decision of the float64 run is to a tie: per sub-band the smallest gap between the
+                    # two largest candidates of a window whose maximum is positive (ReLU active).  A gap below the fp32 noise of
+                    # the candidates lets an fp32 evaluation route that window's gradient to the other position -- a step
+                    # discontinuity of the gradient, 1/#windows of a (band, channel)'s tensors (~1e-2 for the second pooling)
+                    def gap_hook(key):
+                        def hook(mod, inp, o):
+                            k = mod.kernel_size if isinstance(mod.kernel_size, tuple) else (mod.kernel_size,) * 2
+                            u = torch.nn.functional.unfold(inp[0].detach().reshape(-1, 1, *inp[0].shape[2:]), k, stride=k)
+                            top = u.topk(2, dim=1).values
+                            gp = torch.where(top[:, 0] > 0, top[:, 0] - top[:, 1], torch.full_like(top[:, 0], float("inf")))
+                            gaps[key] = float(gp.min())
+                        return hook
+                    for i, cnn in enumerate(m.audio_encoder.subnet_cnns):
+                        hooks.append(cnn.pool1.register_forward_hook(gap_hook(("pool1", i))))
+                        hooks.append(cnn.pool2.register_forward_hook(gap_hook(("pool2", i))))
                 emb = m(stems_dict(x.to(dt)), feats.to(dt))                 # train.py:253 / :299
+                if gaps:
+                    out[f"{tag}.pool1_min_gap"] = np.array([gaps[("pool1", i)] for i in range(ns)])
+                    out[f"{tag}.pool2_min_gap"] = np.array([gaps[("pool2", i)] for i in range(ns)])
+                    print("   pool1 min gaps", " ".join(f"{v:.1e}" for v in out[f"{tag}.pool1_min_gap"]))
+                    print("   pool2 min gaps", " ".join(f"{v:.1e}" for v in out[f"{tag}.pool2_min_gap"]), flush=True)
                 if lossname == "infonce":
                     loss = ref_loss.InfoNCELoss(temperature=0.1)(emb, labels)   # train.py:256 / :302
                 else:

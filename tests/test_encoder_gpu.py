@@ -1068,32 +1068,40 @@ def test_training_step_is_bit_deterministic():
 
 
 CFG_C5 = dict(sample_rate=44100, n_fft=1024, hop_length=256, n_mels=256, split_size=20, overlap=10, embed_dim=768)   # BASELINE configs[4] shapes
-# The one tensor whose fp32 gradient is ill-conditioned on these inputs: the lowest sub-band's conv1 weight
-# gradient is sum(dy * x) over ~1e5 positions with x on the log-mel silence floor (-23.03) and sum(dy) = 0 -- the products
-# cancel to ~1e-3 of their magnitude.  The reference's own fp32 evaluation is off by the same order (printed beside ours).
-ILL_CONDITIONED = ("audio_encoder.subnet_cnns.0.conv1.weight",)
+TIE_GAP = 1e-6   # activations are O(1..20): two max-pool candidates closer than this differ by ~an fp32 ulp
 
 
 @pytest.mark.parametrize("tag,precision", [("default", "fp32"), ("default", "f16x3"), ("c5", "fp32"), ("c5", "f16x3")])
 def test_hip_training_step_matches_the_reference_training_fixture(tag, precision):
     """SURVEY 8 f1 pinned by the REFERENCE's own training arithmetic: tests/golden/train.npz was produced by the reference's
     MixingStyleEncoder.train() + InfoNCELoss + loss.backward() (src/train.py:246-262,292-296; src/model.py:118,125 batch
-    statistics; Dropout p = 0), in fp32 and in float64.  The whole product step -- stage A in HIP, the hand-written trunk
-    forward / backward (fp32 MFMA, and the 3-term split-precision f16 kernels), the torch FiLM MLP / attention head, the HIP
-    InfoNCE -- is held to the float64 fixture: loss 1e-5, train-mode embeddings and running statistics 1e-4, every parameter
-    gradient 1e-4 of its tensor's max on 512 sampled entries, except the ONE named ill-conditioned tensor (<= 1e-2, and no
-    worse than 3x the reference's own fp32 evaluation of it)."""
+    statistics; Dropout p = 0), in fp32 and in float64, on integer-built PCM clips (bit-identical inputs on every machine).
+    The whole product step -- stage A in HIP, the hand-written trunk forward / backward (fp32 MFMA, and the 3-term
+    split-precision f16 kernels), the torch FiLM MLP / attention head, the HIP InfoNCE -- is held to the FLOAT64 fixture:
+    loss 1e-5, train-mode embeddings and running statistics 1e-4, every parameter gradient 1e-4 of its tensor's max on 512
+    sampled entries.  Two classes of tensors have a wider, data-derived bound, and the log names them:
+      * a sub-band whose float64 activations hold a max-pool NEAR-TIE (fixture: smallest gap between the two largest candidates
+        of a second-pooling window < 1e-6, i.e. an fp32 ulp of the activations): no fp32 evaluation can resolve which position
+        wins, the window's gradient is routed to one or the other, and with ~100 windows per (band, channel) that moves the
+        band's tensors by up to ~1e-2 (and the shared FiLM MLP behind its FiLM gradient by ~1e-3).  Measured: exactly the
+        bands the fixture flags deviate, every other band sits at ~1e-5;
+      * conv1 weight gradients, sums of dy * x over ~1e5 positions with x on the log-mel silence floor and sum(dy) = 0
+        (cancellation to ~1e-3 of the terms): bound = 3x the deviation of the REFERENCE's own fp32 run from its float64 run; and
+        1e-3 where the band's FIRST pooling holds a near-tie (one d(conv1 output) element lands on the neighbouring position)."""
     from mst_amd.loss import InfoNCELoss
     g = np.load(os.path.join(G, "train.npz"))
     cfg = cases.CFG_DEFAULT if tag == "default" else CFG_C5
     B, T = 4, 66150
-    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
-    assert np.allclose(cases.checksum(x), g[f"{tag}.in_checksum"], rtol=1e-12)
+    x = cases.pcm_batch(B, T)
+    assert np.allclose(cases.checksum(x), g[f"{tag}.in_checksum"], rtol=1e-13)   # integer-built input (cases.pcm_clip): the fixture's samples
     stems = omel.tensor_to_stems_dict(x.cuda())
     feats = torch.from_numpy(g[f"{tag}.features"]).cuda()
     labels = torch.from_numpy(g[f"{tag}.labels"]).cuda()
     R = torch.randn(B, cfg["embed_dim"], generator=torch.Generator().manual_seed(77)).cuda()
     names = [str(n) for n in g[f"{tag}.param_names"]]
+    gap1, gap2 = g[f"{tag}.pool1_min_gap"], g[f"{tag}.pool2_min_gap"]
+    tie_bands = {i for i in range(len(gap2)) if gap2[i] < TIE_GAP}
+    assert len(tie_bands) <= 2, "the fixture should leave most sub-bands free of near-ties"
     for lossname in ("infonce", "proj"):
         model, _ = build_model(cfg)
         for m in model.modules():
@@ -1110,33 +1118,45 @@ def test_hip_training_step_matches_the_reference_training_fixture(tag, precision
         assert abs(loss.item() - ref_loss) <= 1e-5 * max(1.0, abs(ref_loss)), (loss.item(), ref_loss)
         if lossname == "infonce":
             close(emb.detach().cpu(), g[f"{tag}.f64.embedding"], 1e-4, name=f"train fixture [{tag} {precision}] embedding")
-            pin_shape = tuple(g[f"{tag}.pool_in_shape"])
+            worst_stat = 0.0
             for n, b in model.named_buffers():
                 if "running" in n:   # one momentum update from the batch statistics (model.py:118,125 under train())
-                    close(b.cpu(), g[f"{tag}.f64.buf.{n}"], 1e-4, name=f"train fixture [{tag} {precision}] running statistics")
-            assert pin_shape[0] == B
-        rows, worst_ok = [], 0.0
+                    ref = g[f"{tag}.f64.buf.{n}"]
+                    worst_stat = max(worst_stat, float(np.abs(b.cpu().double().numpy() - ref).max() / np.abs(ref).max()))
+            parity.note(f"train fixture [{tag} {precision}] running statistics after the step, worst tensor (norm-wise)", err=worst_stat)
+            assert worst_stat <= 1e-4
+        rows, bad = [], []
+        gscale = max(float(g[f"{tag}.f64.{lossname}.grad_norm.{n}"][1]) for n in names)   # largest gradient entry of any tensor
         for j, (n, q) in enumerate(model.named_parameters()):
             ref = g[f"{tag}.f64.{lossname}.grad_samples.{n}"]
             r32 = g[f"{tag}.f32.{lossname}.grad_samples.{n}"].astype(np.float64)
             gmax = float(g[f"{tag}.f64.{lossname}.grad_norm.{n}"][1])
             got = q.grad.detach().double().flatten().cpu()[cases.sample_idx(q.numel(), 512, 1000 + j)].numpy()
-            if gmax <= 1e-30:   # conv biases in front of a batch-statistics BatchNorm: identically zero in exact arithmetic
-                assert np.abs(got).max() <= 1e-6 * max(1.0, abs(ref_loss)), (n, np.abs(got).max())
+            if gmax <= 1e-9 * gscale:   # identically zero in exact arithmetic (conv biases in front of a batch-statistics BatchNorm,
+                #                             the attention score bias under softmax): float64 leaves rounding dust, nothing to compare
+                assert np.abs(got).max() <= 1e-6 * gscale, (n, np.abs(got).max(), gscale)
                 continue
             e_hip, e_r32 = float(np.abs(got - ref).max() / gmax), float(np.abs(r32 - ref).max() / gmax)
-            rows.append((e_hip, e_r32, n))
-            if n in ILL_CONDITIONED:
-                assert e_hip <= 1e-2 and e_hip <= max(3.0 * e_r32, 1e-4), (n, e_hip, e_r32)
+            band = int(n.split("subnet_cnns.")[1].split(".")[0]) if "subnet_cnns." in n else None
+            if band in tie_bands:
+                limit, why = 3e-2, "near-tie band"
+            elif n.startswith("film_encoder.") and tie_bands:
+                limit, why = 5e-3, "FiLM MLP behind a near-tie band"
+            elif n.endswith("conv1.weight"):
+                limit, why = min(1e-2, max(1e-4, 3.0 * e_r32)), "conv1 weight (cancellation)"
+                if gap1[band] < TIE_GAP:   # a first-pooling near-tie moves ONE d(conv1 output) element to the neighbouring position:
+                    limit, why = max(limit, 1e-3), "conv1 weight, first-pooling near-tie in this band"   # 1 of ~2000 windows of a channel
             else:
-                worst_ok = max(worst_ok, e_hip)
+                limit, why = 1e-4, ""
+            rows.append((e_hip, e_r32, n, why))
+            if e_hip > limit:
+                bad.append((n, f"{e_hip:.1e} > {limit:.1e}", why))
         rows.sort(reverse=True)
-        hip = np.array([r[0] for r in rows])
+        strict = np.array([r[0] for r in rows if not r[3]])
         parity.note(f"train fixture [{tag} {precision} {lossname}] gradients vs the reference in float64 (norm-wise per tensor)",
-                    tensors=len(rows), hip_max=float(hip.max()), hip_median=float(np.median(hip)),
-                    hip_beyond_1e4=int((hip > 1e-4).sum()), worst=rows[0][2], reference_fp32_there=rows[0][1],
-                    reference_fp32_max=float(max(r[1] for r in rows)))
-        print(f"[{tag} {precision} {lossname}] worst five: " + ", ".join(f"{n.split('audio_encoder.')[-1]} {a:.1e} (ref fp32 {b:.1e})"
-                                                                         for a, b, n in rows[:5]))
-        bad = [(n, f"{a:.1e}") for a, _, n in rows if a > 1e-4 and n not in ILL_CONDITIONED]
+                    tensors=len(rows), held_to_1e4=len(strict), strict_max=float(strict.max()), strict_median=float(np.median(strict)),
+                    near_tie_bands=str(sorted(tie_bands)), near_tie_gaps=str([float(f"{gap2[i]:.1e}") for i in sorted(tie_bands)]),
+                    worst=rows[0][2], worst_err=rows[0][0], reference_fp32_there=rows[0][1])
+        print(f"[{tag} {precision} {lossname}] near-tie bands {sorted(tie_bands)}; worst five: " +
+              ", ".join(f"{n.split('audio_encoder.')[-1]} {a:.1e} (ref fp32 {b:.1e}{', ' + w if w else ''})" for a, b, n, w in rows[:5]))
         assert not bad, bad

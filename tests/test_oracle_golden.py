@@ -243,8 +243,8 @@ def test_training_oracle_is_pinned_by_the_reference_training_step(tag, lossname)
     g = load("train.npz")
     cfg = cases.CFG_DEFAULT if tag == "default" else CFG_C5
     B, T = 4, 66150
-    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
-    assert np.allclose(cases.checksum(x), g[f"{tag}.in_checksum"], rtol=1e-12)
+    x = cases.pcm_batch(B, T)
+    assert cases.checksum(x) == g[f"{tag}.in_checksum"].tolist()   # integer-built input: exact on every machine
     feats = torch.from_numpy(g[f"{tag}.features"])
     labels = torch.from_numpy(g[f"{tag}.labels"])
     R = torch.randn(B, cfg["embed_dim"], generator=torch.Generator().manual_seed(77))
