@@ -667,19 +667,8 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 #pragma unroll
   for (int i = 0; i < NPF; ++i) prefetch_piece(i);
 
-  for (int s = s_begin; s < s_end; ++s) {
-    cur = nxt;
-    if (cur.band != cur_band) {  // same `s` sequence in every wave: all eight reach this together
-      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
-      __syncthreads();
-      for (int c = 0; c < 2; ++c) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)cur.band * 2 + c) * WBP);
-        for (int k = tid; k < WCH / 4; k += kConvThreads) reinterpret_cast<f32x4*>(wres + c * WCH)[k] = src[k];
-      }
-      __syncthreads();
-      cur_band = cur.band;
-    }
-    // stage this wave's prefetched patch (wave-private: no barrier)
+  // stage this wave's prefetched patch (wave-private: no barrier)
+  auto stage = [&]() __attribute__((always_inline)) {
     if constexpr (LAY == 0) {
 #pragma unroll
       for (int i = 0; i < NPF; ++i)
@@ -695,9 +684,25 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         }
       }
     }
+  };
+  // (staging the NEXT tile's patch before this tile's epilogue -- so that no tile opens behind the acknowledgement of the previous
+  // tile's stores in the in-order vmcnt counter -- measured 0.7 % SLOWER here: the 31 k MFMA cycles of a tile dwarf that wait)
+  for (int s = s_begin; s < s_end; ++s) {
+    cur = nxt;
+    if (cur.band != cur_band) {  // same `s` sequence in every wave: all eight reach this together
+      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
+      __syncthreads();
+      for (int c = 0; c < 2; ++c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)cur.band * 2 + c) * WBP);
+        for (int k = tid; k < WCH / 4; k += kConvThreads) reinterpret_cast<f32x4*>(wres + c * WCH)[k] = src[k];
+      }
+      __syncthreads();
+      cur_band = cur.band;
+    }
+    stage();
     nxt = decode(s + 1);
     prefetch_setup(nxt);
-    if (!cur.valid) {  // ragged tail of the band: nothing to compute, but keep the prefetch chain alive
+    if (!cur.valid) {
 #pragma unroll
       for (int i = 0; i < NPF; ++i) prefetch_piece(i);
       continue;
@@ -1156,6 +1161,274 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
   if (MODE >= 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// conv1 on the f16 matrix cores, EVAL path, channel-minor float16 input (MST_LOGMEL_CM16): the bank-conflict-free build.
+// conv1_f16x3_kernel's A-fragment reads (one ds_read_b128 per (M-tile, k-step): 16 lanes per LDS cycle, conflict-free only
+// if their 16-byte units are distinct mod 16) ran at 8.3 LDS cycles instead of 4 -- SQ_LDS_BANK_CONFLICT 44 % of the LDS
+// cycles, LDS busier than the matrix pipe in the plain-f16 mode.  Three changes make every read conflict-free:
+//   * A row (lane & 15) = 4 g + 2 dr + dc of M-tile t  <->  position (row dr, column 10 g + 2 t + dc) of the 2 x 40 tile: the
+//     four rows of a lane group are a 2 x 2 block, M-tile t walks the group's ten columns in pairs -- every 2 x 5 pooling
+//     window still sits in ONE lane's accumulators (tile t = 2 holds the last column of window 0 and the first of window 1);
+//   * the patch keeps its even rows at units [0, 4 RS) and its odd rows 8 units further on ((4 RS + 8) from the even part,
+//     RS = 48): a 2 x 2 block touches units {c, c + 1, c + 8, c + 9} mod 16, and the four lane groups (columns 10 g) then fill
+//     all 16 residues: {0, 10, 4, 14} + {0, 1, 8, 9} = Z_16;
+//   * a k-step is ONE tap column and four tap rows, dealt to the k-groups (lane >> 4) as rows (0, 2, 1, 3): the two k-groups
+//     that share an LDS cycle differ by two rows = 0 mod 16 units.  7 tap columns x (rows 0..3, rows 4..6 + one zero slot)
+//     = 14 k-steps (13 in the other kernel: + 7.7 % MFMAs, all addresses are lane base + immediate).
+// Same epilogue arithmetic; the fp32 sums run over the taps in a different order than conv1_f16x3_kernel's.
+// ------------------------------------------------------------------------------------------
+constexpr int kF16StepsE = 14;
+constexpr int kF16eRS = 48, kF16eOdd = 4 * kF16eRS + 8, kF16ePatch = kF16eOdd + 4 * kF16eRS;   // units (16 bytes) per patch part
+
+// Waves per workgroup: 8 with split precision (hi + lo patches: 152 KB of LDS); 12 with plain f16 (104 KB, 3 waves per SIMD on
+// <= 168 registers: the third wave covers what two leave open -- per tile a wave has 2240 cycles of MFMAs and about as many of
+// staging, epilogue and tile bookkeeping).
+template <int TERMS> constexpr int kF16eWaves = TERMS == 1 ? 12 : 8;
+template <int TERMS>
+__global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(const ConvParams p, const h16x8* __restrict__ wfrag16,
+                                                                 _Float16* __restrict__ out_hi, _Float16* __restrict__ out_lo) {
+  using C = CC<1, 2>;
+  constexpr int MT = C::MT, NT = C::NT, PR = C::PR, PC = C::PC;
+  static_assert(PR == 8 && PC <= kF16eRS && MT == 5, "2 x 40 tiles with halo 3");
+  constexpr int HL = TERMS == 3 ? 2 : 1, NW = kF16eWaves<TERMS>, NTHR = NW * 64;
+  constexpr int WVG = kF16StepsE * NT * 2 * 64;       // h16x8 vectors of one band's weights in global memory: [step][nt][hi/lo][lane]
+  constexpr int WV = kF16StepsE * NT * HL * 64;       // ... staged into LDS (plain f16: the high parts only)
+  constexpr int NPF = (PC + 7) / 8;                   // 8 rows x 8 frames per load instruction
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  h16x8* wres = reinterpret_cast<h16x8*>(smem);                       // [WV]
+  h16x8* phi = wres + WV + wave * HL * kF16ePatch;                     // wave-private patch, hi part
+  h16x8* plo = phi + kF16ePatch;                                       //                     lo part (TERMS 3)
+
+  const int G = gridDim.x;
+  const int wg = mst::xcd_remap(blockIdx.x, G);
+  const int total_sets = p.nsub * p.sets_per_band;
+  const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
+  const int tpb = p.tiles_r * p.tiles_c;
+  auto decode = [&](int s) __attribute__((always_inline)) {   // with integer divisions: at the start and at band changes only
+    Tile t;
+    t.band = min(s / p.sets_per_band, p.nsub - 1);
+    const int idx = (s - t.band * p.sets_per_band) * NW + wave;
+    t.valid = (s < s_end) && idx < p.B * tpb;
+    t.clip = idx / tpb;
+    const int ti = idx - t.clip * tpb;
+    t.tc = ti / p.tiles_r;
+    t.tr = ti - t.tc * p.tiles_r;
+    if (!t.valid) t.clip = t.tc = t.tr = 0;
+    return t;
+  };
+  // the wave's next tile is 8 tiles further on in (clip, tile column, tile row) order: carried on the scalar unit without the
+  // three divisions of decode() (~190 scalar instructions per tile, a fifth of the plain-f16 tile's MFMA time)
+  int sib = 0;   // set index inside the band
+  auto advance = [&](const Tile& c, int s_next) __attribute__((always_inline)) {
+    Tile t = c;
+    if (++sib == p.sets_per_band || s_next >= s_end || !c.valid) {
+      t = decode(s_next);
+      sib = s_next - t.band * p.sets_per_band;
+      return t;
+    }
+    t.tr += NW;
+    while (t.tr >= p.tiles_r) t.tr -= p.tiles_r, ++t.tc;
+    while (t.tc >= p.tiles_c) t.tc -= p.tiles_c, ++t.clip;
+    t.valid = t.clip < p.B;
+    if (!t.valid) t.clip = t.tc = t.tr = 0;
+    return t;
+  };
+
+  // A-fragment addressing: unit(r, c) = (r >> 1) * RS + (r & 1) * kF16eOdd + c.  Lane: k-group kq -> tap row kqr (+ 4 in odd
+  // steps), A row -> (g, dr, dc).  r = dr + kqr + rb with rb in {0, 4} compile-time; the zero slot (tap row 7: odd steps,
+  // kq = 3) reads tap row 6 again (its weights are zero; the address must stay inside the patch)
+  const int kq = lane >> 4, ai = lane & 15, ag = ai >> 2, adr = (ai >> 1) & 1, adc = ai & 1;
+  const int kqr = ((kq & 1) << 1) | (kq >> 1);          // 0, 2, 1, 3
+  const int q0 = adr + kqr, q1 = adr + (kq == 3 ? 2 : kqr);
+  const int base0 = (q0 >> 1) * kF16eRS + (q0 & 1) * kF16eOdd + 10 * ag + adc;                       // even steps (tap rows 0..3)
+  const int base1 = ((q1 >> 1) + 2) * kF16eRS + (q1 & 1) * kF16eOdd + 10 * ag + adc;                 // odd steps (tap rows 4..6, 6)
+
+  h16x8 pf[NPF], pfl[TERMS == 3 ? NPF : 1];
+  unsigned rowmask = 0;
+  bool row_ok = false;
+  int coff = 0, frame0 = 0, nvalid = 0;
+  const char* nsrc = static_cast<const char*>(static_cast<const void*>(p.in));
+  const char* nsrc_lo = static_cast<const char*>(p.in_lo);
+  // loader: lane = 8 r + fq -> patch row r, frames fq + 8 i (piece i): a wave instruction reads 8 frames x 128 contiguous bytes
+  // and its 8 lanes per LDS write cycle store 8 consecutive units of one row
+  const int lr = lane >> 3, lfq = lane & 7;
+  const unsigned frame_bytes = (unsigned)p.cm_mels * 16u;
+  auto prefetch_setup = [&](const Tile& t) __attribute__((always_inline)) {
+    const int rin = C::TROWS * t.tr - 3 + lr, rc = min(max(rin, 0), p.in_rows - 1);
+    nvalid = t.valid;
+    rowmask = 0;
+    const size_t cb = (size_t)t.clip * p.in_clipstride * 2;                 // bytes: in_clipstride counts float16 elements
+    nsrc = static_cast<const char*>(static_cast<const void*>(p.in)) + cb;   // wave-uniform clip base (high parts)
+    nsrc_lo = static_cast<const char*>(p.in_lo) + cb;
+    row_ok = nvalid && rin == rc;
+    coff = (t.band * p.cm_overlap + rc) * 16;
+    frame0 = C::TCOLS * t.tc - 3 + lfq;
+  };
+  auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
+    if (i < NPF) {
+      const int fin = frame0 + 8 * i, fc = min(max(fin, 0), p.in_cols - 1);
+      if (row_ok && fin == fc) rowmask |= 1u << i;
+      const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
+      pf[i] = *reinterpret_cast<const h16x8*>(nsrc + boff);
+      if (TERMS == 3) pfl[i] = *reinterpret_cast<const h16x8*>(nsrc_lo + boff);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  int cur_band = -1;
+  Tile cur{}, nxt = decode(s_begin);
+  sib = s_begin - nxt.band * p.sets_per_band;
+  prefetch_setup(nxt);
+#pragma unroll
+  for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+
+  // stage the prefetched patch: one 16-byte vector per position, rows split into the even and the odd part
+  auto stage = [&]() __attribute__((always_inline)) {
+    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int wbase = (lr >> 1) * kF16eRS + (lr & 1) * kF16eOdd + lfq;
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+      if (8 * i + 7 < PC || 8 * i + lfq < PC) {
+        const bool ok = (rowmask >> i) & 1u;
+        phi[wbase + 8 * i] = ok ? pf[i] : z;
+        if (TERMS == 3) plo[wbase + 8 * i] = ok ? pfl[i] : z;
+      }
+    }
+  };
+  // Order inside a tile: k-steps (the next tile's patch is fetched meanwhile) -> stage the NEXT tile's patch -> this tile's
+  // epilogue.  Staging waits for the prefetched loads with a vmcnt wait, and stores count in the same in-order counter: with the
+  // epilogue first, every tile opened by sitting out the acknowledgement of the previous tile's output stores.
+  stage();
+  for (int s = s_begin; s < s_end; ++s) {
+    cur = nxt;
+    if (cur.band != cur_band) {
+      __syncthreads();
+      const h16x8* src = wfrag16 + (size_t)cur.band * WVG;
+      for (int k = tid; k < WV; k += NTHR) wres[k] = HL == 2 ? src[k] : src[((k >> 6) * 2) * 64 + (k & 63)];
+      __syncthreads();
+      cur_band = cur.band;
+    }
+    nxt = advance(cur, s + 1);
+    prefetch_setup(nxt);
+    if (!cur.valid) {   // ragged tail of a band: nothing to compute, but the next tile's patch must be in place
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+      stage();
+      continue;
+    }
+    // the epilogue's per-(clip, band, channel) constants: requested NOW, used after the k-steps (fetched in the epilogue their
+    // global-memory round trips stood in the open once per tile)
+    float2 e_ac[NT];
+    float e_winv[NT];
+    {
+      const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        e_ac[n] = aff[n * 16 + (lane & 15)];
+        e_winv[n] = p.f16_winv[cur.band * C::COUT + n * 16 + (lane & 15)];
+      }
+    }
+    float f16s = p.f16_scale ? p.f16_scale[((size_t)cur.clip * p.nsub + cur.band) * 2] : 1.0f;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // fragments of k-step st + 1 are read from LDS while the MFMAs of step st run (double-buffered registers); every A address
+      // is a lane base (even / odd steps) plus a compile-time offset: tap column st >> 1, M-tile column pair 2 t
+      constexpr bool DB = true;
+      h16x8 ah[DB ? 2 : 1][MT], al[DB ? 2 : 1][MT], bh[DB ? 2 : 1][NT], bl[DB ? 2 : 1][NT];
+      auto read_step = [&](int st, int buf) __attribute__((always_inline)) {
+        const h16x8* pa = phi + ((st & 1) ? base1 : base0) + (st >> 1);
+        const h16x8* pl = plo + ((st & 1) ? base1 : base0) + (st >> 1);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          bh[buf][n] = wres[((st * NT + n) * HL + 0) * 64 + lane];
+          if (TERMS == 3) bl[buf][n] = wres[((st * NT + n) * HL + 1) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          ah[buf][t] = pa[2 * t];
+          if (TERMS == 3) al[buf][t] = pl[2 * t];
+        }
+      };
+      if (DB) read_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < kF16StepsE; ++st) {
+        const int cu = DB ? (st & 1) : 0, nx = cu ^ 1;
+        if (!DB) read_step(st, 0);
+        else if (st + 1 < kF16StepsE) read_step(st + 1, nx);
+        prefetch_piece(st);                                       // 6 (+ 6) 16-byte loads of the next tile, in the first six steps
+        // pin the reads IN FRONT of this step's MFMAs: left to itself the scheduler sinks them into the middle of the step and the
+        // next step opens with an exposed LDS round trip (counted lgkmcnt waits two MFMAs after the reads)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (TERMS == 3) {
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);  // small terms first
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bl[cu][n], acc[t][n], 0, 0, 0);
+            }
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
+      }
+    }
+    stage();   // the next tile's patch (this tile's LDS reads are all consumed)
+    // (the constants are first TOUCHED here: without this the scheduler folds the weight pre-scale into the affine right after
+    // the loads and the wave sits out their round trip at the head of the tile)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) asm volatile("" : "+v"(e_ac[n].x), "+v"(e_ac[n].y), "+v"(e_winv[n]));
+    asm volatile("" : "+v"(f16s));
+    {   // epilogue: y = A * acc + C, ReLU, max over the window -- accumulator slot (t, r) is position (row r >> 1, column
+        // 10 g + 2 t + (r & 1)): columns 0..4 of the lane's ten are pooling window 0, columns 5..9 window 1
+      const int j = lane & 15, g = lane >> 4;
+      float* orow = p.out + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT * p.out_rows * p.out_cols +
+                    (size_t)cur.tr * p.out_cols;
+      const int nh = p.pool_h == 1 ? 2 : 1;   // pool height 1 (16-mel sub-bands): two 1 x 5 windows (tile rows 0 and 1) per window column block
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = n * 16 + j;
+        float2 ac = e_ac[n];
+        ac.x *= e_winv[n];  // undo the weight pre-scale
+#pragma unroll
+        for (int wv = 0; wv < 2; ++wv) {
+          const int pc = 8 * cur.tc + 2 * g + wv;
+#pragma unroll
+          for (int hr = 0; hr < 2; ++hr) {
+            if (hr < nh) {
+              float m = 0.f;   // ReLU floor
+#pragma unroll
+              for (int cc = 5 * wv; cc < 5 * wv + 5; ++cc)
+#pragma unroll
+                for (int dr = 0; dr < 2; ++dr) {
+                  const bool mine = nh == 1 || dr == hr;
+                  const float v = fmaf(acc[cc >> 1][n][2 * dr + (cc & 1)], ac.x, ac.y);
+                  m = mine ? fmaxf(m, v) : m;
+                }
+              const int orow_i = nh == 1 ? cur.tr : 2 * cur.tr + hr;   // output row
+              if (pc < p.out_cols && orow_i < p.out_rows) {
+                if (p.out) orow[(size_t)ch * p.out_rows * p.out_cols + (size_t)(orow_i - cur.tr) * p.out_cols + pc] = m;
+                if (out_hi) {  // conv2's split-precision input: [clip][band][row][col][32 ch] f16, hi and lo, range-scaled
+                  const size_t o = ((((size_t)cur.clip * p.nsub + cur.band) * p.out_rows + orow_i) * p.out_cols + pc) * 32 + ch;
+                  const float ms = m * f16s;
+                  const _Float16 h = (_Float16)ms;
+                  out_hi[o] = h;
+                  if (TERMS == 3) out_lo[o] = (_Float16)(ms - (float)h);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // OPT-IN conv2 on the f16 matrix cores, 3-term split precision (mst_encoder_set_precision(enc, 2)).
 // Input: conv1's pooled activations as f16 hi/lo, channel-minor.  A k-step is 4 taps x 8 input channels; the 32
@@ -1587,6 +1860,7 @@ struct mst_encoder {
   float att2_b = 0.f;
   int num_cus = 256;
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
+  void* w1frag16e = nullptr;  // the same weights in conv1_f16e_kernel's k order (14 steps: one tap column x four tap rows)
   void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
   float* w1norm = nullptr;    // [nsub][32] L1 norm of every conv1 filter (range bound of the f16 path)
   float *f16_winv1 = nullptr, *f16_winv2 = nullptr;   // [nsub][32], [nsub][64]: inverse pre-scale of the f16 weight fragments
@@ -2646,6 +2920,20 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
             f16[base + (size_t)lane * 8 + j] = h;
             f16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(wv - (float)h);
           }
+  // ... and in the k order of conv1_f16e_kernel: step = (tap column, upper / lower tap rows), k-group kq -> tap row (0, 2, 1, 3)
+  std::vector<_Float16> f16e((size_t)ns * kF16StepsE * 2 * 2 * 64 * 8);
+  for (int b = 0; b < ns; ++b)
+    for (int st = 0; st < kF16StepsE; ++st)
+      for (int n = 0; n < 2; ++n)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int kq = lane >> 4, tr = 4 * (st & 1) + (((kq & 1) << 1) | (kq >> 1)), tc = st >> 1, co = n * 16 + (lane & 15);
+            const float wv = tr < 7 ? ldexpf(w->conv1_w[(((size_t)b * 32 + co) * 8 + j) * 49 + tr * 7 + tc], wex1[(size_t)b * 32 + co]) : 0.f;
+            const _Float16 h = (_Float16)wv;
+            const size_t base = ((((size_t)b * kF16StepsE + st) * 2 + n) * 2) * 64 * 8;
+            f16e[base + (size_t)lane * 8 + j] = h;
+            f16e[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(wv - (float)h);
+          }
   std::vector<_Float16> g16((size_t)ns * 4 * kF16Steps * 4 * 2 * 64 * 8);
   for (int b = 0; b < ns; ++b)
     for (int ck = 0; ck < 4; ++ck)
@@ -2669,10 +2957,11 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
     }
   int rc = 0;
   {
-    _Float16 *d16 = nullptr, *e16 = nullptr;
+    _Float16 *d16 = nullptr, *e16 = nullptr, *d16e = nullptr;
     rc = mst::upload(&d16, f16.data(), f16.size());
     if (!rc) rc = mst::upload(&e16, g16.data(), g16.size());
-    e->w1frag16 = d16, e->w2frag16 = e16;
+    if (!rc) rc = mst::upload(&d16e, f16e.data(), f16e.size());
+    e->w1frag16 = d16, e->w2frag16 = e16, e->w1frag16e = d16e;
   }
 #define UP(dst, vec) if (!rc) rc = mst::upload(&e->dst, (vec).data(), (vec).size())
 #define UPP(dst, ptr, n) if (!rc) rc = mst::upload(&e->dst, ptr, (size_t)(n))
@@ -2711,7 +3000,7 @@ void mst_encoder_destroy(mst_encoder* e) {
                    e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b, e->c1b, e->bn1w, e->bn1b, e->c2b,
                    e->bn2w, e->bn2b, e->w2dfrag};
   for (float* q : ptrs) (void)hipFree(q);
-  (void)hipFree(e->w1frag16);
+  (void)hipFree(e->w1frag16), (void)hipFree(e->w1frag16e);
   (void)hipFree(e->w1norm), (void)hipFree(e->f16_winv1), (void)hipFree(e->f16_winv2);
   (void)hipFree(e->w2frag16);
   (void)hipFree(e->w2dfrag16);
@@ -2833,6 +3122,9 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
       }
       const int g = std::min(grid, ns * cp.sets_per_band);
       constexpr size_t lds = (size_t)(kF16Steps * C::NT * 2 * 64 + kConvWaves * 2 * C::PR * C::PC) * 16;
+      constexpr size_t lds_e3 = (size_t)(kF16StepsE * C::NT * 2 * 64 + kConvWaves * 2 * kF16ePatch) * 16;   // conv1_f16e_kernel
+      constexpr size_t lds_e1 = (size_t)(kF16StepsE * C::NT * 64 + kF16eWaves<1> * kF16ePatch) * 16;
+      static_assert(lds_e3 <= 160 * 1024, "conv1_f16e_kernel<3> must fit one CU's LDS");
       static unsigned long long attr16 = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr16)) {
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3>),
@@ -2841,11 +3133,11 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err == hipSuccess)
-          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3, 0, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16e_kernel<3>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e3);
         if (err == hipSuccess)
-          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 0, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16e_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e1);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 f16x3 attribute failed: %s", hipGetErrorString(err));
       }
       const bool both = e->conv1_f16x3 >= 2;
@@ -2867,9 +3159,14 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
       _Float16* oh = both ? reinterpret_cast<_Float16*>(ws + L.pool1_h16) : nullptr;
       _Float16* ol = e->conv1_f16x3 == 2 ? reinterpret_cast<_Float16*>(ws + L.pool1_l16) : nullptr;
-      if (lay == MST_LOGMEL_CM16) {
-        if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 0, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
-        else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 0, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
+      if (lay == MST_LOGMEL_CM16) {   // the bank-conflict-free build (its own k order: w1frag16e)
+        const h16x8* wfe = reinterpret_cast<const h16x8*>(e->w1frag16e);
+        if (e->conv1_f16x3 == 3) {   // plain f16: 12 waves per workgroup, sets of 12 tiles
+          cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kF16eWaves<1> - 1) / kF16eWaves<1>;
+          const int g1 = std::min(grid, ns * cp.sets_per_band);
+          hipLaunchKernelGGL((conv1_f16e_kernel<1>), dim3(g1), dim3(kF16eWaves<1> * 64), lds_e1, st, cp, wfe, oh, ol);
+        }
+        else hipLaunchKernelGGL((conv1_f16e_kernel<3>), dim3(g), dim3(kConvThreads), lds_e3, st, cp, wfe, oh, ol);
       } else if (e->conv1_f16x3 == 3) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, oh, ol);
       err = hipGetLastError();

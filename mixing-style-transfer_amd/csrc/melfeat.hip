@@ -24,9 +24,6 @@
 #include <cmath>
 #include <vector>
 
-#ifndef MST_ABLATE
-#define MST_ABLATE 0   // timing-only builds: 1 no mel gather, 2 +no real-FFT split, 3 +no FFT passes, 4 +no global loads
-#endif
 
 namespace {
 
@@ -90,13 +87,10 @@ __device__ __forceinline__ float2 shfl2(float2 a, int src) {
 
 // Sample type of the waveform in HBM: fp32, or int16 PCM (the ingest format: half the PCIe / HBM bytes; converted
 // with the exact scale 2^-15, so the result equals the fp32 path run on float(pcm) / 32768 bit for bit).
-#ifndef MST_V2_NT
-#define MST_V2_NT 0   // experiment switch: bit 0 streaming (non-temporal) sample loads, bit 1 non-temporal log-mel stores
-#endif
 template <typename ST> struct Smp;
 template <> struct Smp<float> {
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
-  static __device__ __forceinline__ float lds(const float* p) { return (MST_V2_NT & 1) ? __builtin_nontemporal_load(p) : *p; }
+  static __device__ __forceinline__ float lds(const float* p) { return *p; }
   static __device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
   static __device__ __forceinline__ void ld4(const float* p, float (&x)[4]) {
     const float4 q = *reinterpret_cast<const float4*>(p);
@@ -107,7 +101,7 @@ template <> struct Smp<short> {
   static constexpr float kScale = 1.0f / 32768.0f;
   static __device__ __forceinline__ float ld(const short* p) { return (float)*p * kScale; }
   static __device__ __forceinline__ float lds(const short* p) {
-    return (float)((MST_V2_NT & 1) ? __builtin_nontemporal_load(p) : *p) * kScale;
+    return (float)(*p) * kScale;
   }
   static __device__ __forceinline__ float2 ld2(const short* p) {
     const short2 q = *reinterpret_cast<const short2*>(p);
@@ -152,7 +146,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const ST* const (&x
         const float2 w = s_win[n];
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          const float2 x = MST_ABLATE >= 4 ? make_float2(0.001f * n, 0.002f * lane) : Smp<ST>::ld2(xchs[f] + s0[f] + 2 * n);
+          const float2 x = Smp<ST>::ld2(xchs[f] + s0[f] + 2 * n);
           v[f][u * R0 + t] = make_float2(x.x * w.x, x.y * w.y);
           if constexpr (RAW) {
             const int q = u + t * NBF0;  // compile-time after unrolling
@@ -179,12 +173,12 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const ST* const (&x
         }
       }
   }
-  if (MST_ABLATE < 3) Plan::template run<NF>(v, scr, s_tw, lane);
+  Plan::template run<NF>(v, scr, s_tw, lane);
 
   // real-FFT split: X[k] = E + W^k O with E,O from Z[k] and conj(Z[NC-k]); P = |X|^2
   const int mirror = (64 - lane) & 63;
 #pragma unroll
-  for (int q = 0; q < (MST_ABLATE >= 2 ? 0 : Q); ++q) {
+  for (int q = 0; q < Q; ++q) {
     auto reg = [](int qq) { return (qq % NBFL) * RL + qq / NBFL; };
     const float2 w = s_post[q * 64 + lane];
 #pragma unroll
@@ -215,7 +209,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const ST* const (&x
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = 0.f;
     const float* w = s_melw + p.goff[r] + lane;
-    const int n = MST_ABLATE >= 1 ? 0 : p.glen[r];
+    const int n = p.glen[r];
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
       const float wi = w[i * 64];
@@ -224,7 +218,7 @@ __device__ __forceinline__ void frames_mel(const KParams& p, const ST* const (&x
       for (int f = 0; f < NF; ++f) acc[f] = fmaf(wi, reinterpret_cast<const float*>(scr + f * SCR)[k], acc[f]);
     }
 #pragma unroll
-    for (int f = 0; f < NF; ++f) mel[f][r] = acc[f] + (MST_ABLATE ? v[f][r].x + v[f][r + 2].y + reinterpret_cast<const float*>(scr + f * SCR)[lane] : 0.f);
+    for (int f = 0; f < NF; ++f) mel[f][r] = acc[f];
   }
 }
 
@@ -270,8 +264,7 @@ __device__ __forceinline__ void frames_mel_cplx(const KParams& p, const ST* __re
       const int n = lane + 64 * u + t * STR0;
       const float w = s_winf[n];
       float a, b;
-      if (MST_ABLATE >= 4) a = 0.001f * n, b = 0.002f * lane;
-      else if (interior) a = Smp<ST>::ld(xa + sA + n), b = Smp<ST>::ld(xb + sB + n);
+      if (interior) a = Smp<ST>::ld(xa + sA + n), b = Smp<ST>::ld(xb + sB + n);
       else a = Smp<ST>::ld(xa + reflect_idx(sA + n, p.T)), b = Smp<ST>::ld(xb + reflect_idx(sB + n, p.T));
       const float aw = a * w, bw = b * w;
       ma = fmaxf(ma, fabsf(aw)), mb = fmaxf(mb, fabsf(bw));
@@ -292,13 +285,13 @@ __device__ __forceinline__ void frames_mel_cplx(const KParams& p, const ST* __re
   }
   const float ia = ua != 0u ? 1.0f : 0.f;
   const float ib = ub != 0u ? __uint_as_float((unsigned)(127 - 2 * sh) << 23) : 0.f;
-  if (MST_ABLATE < 3) Plan::template run<1>(v, scr, s_tw2, lane);
+  Plan::template run<1>(v, scr, s_tw2, lane);
   float* PA = reinterpret_cast<float*>(scr);
   float* PB = PA + PB_OFF;
   const int mirror = (64 - lane) & 63;
   auto reg = [](int qq) { return (qq % NBFL) * RL + qq / NBFL; };
 #pragma unroll
-  for (int q = 0; q < (MST_ABLATE >= 2 ? 0 : Q / 2); ++q) {
+  for (int q = 0; q < Q / 2; ++q) {
     const float2 a = v[0][reg(q)];
     const float2 bo = shfl2(v[0][reg(Q - 1 - q)], mirror);
     const float2 bs = v[0][reg((Q - q) % Q)];
@@ -317,7 +310,7 @@ __device__ __forceinline__ void frames_mel_cplx(const KParams& p, const ST* __re
   for (int r = 0; r < NB; ++r) {
     float a0 = 0.f, a1 = 0.f;
     const float* w = s_melw + p.goff[r] + lane;
-    const int n = MST_ABLATE >= 1 ? 0 : p.glen[r];
+    const int n = p.glen[r];
 #pragma unroll 4
     for (int i = 0; i < n; ++i) {
       const float wi = w[i * 64];
@@ -325,8 +318,8 @@ __device__ __forceinline__ void frames_mel_cplx(const KParams& p, const ST* __re
       a0 = fmaf(wi, PA[k], a0);
       a1 = fmaf(wi, PB[k], a1);
     }
-    mel[0][r] = a0 + (MST_ABLATE ? v[0][r].x + PA[lane] : 0.f);
-    mel[1][r] = a1 + (MST_ABLATE ? v[0][r + 2].y + PB[lane] : 0.f);
+    mel[0][r] = a0;
+    mel[1][r] = a1;
   }
 }
 
@@ -391,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
     for (int s = 0; s < 4; ++s) cr[s] = mid[s] = side[s] = 0.f;
     // all loads of up to kIT iterations are issued before any arithmetic: the pass is latency-bound otherwise
     constexpr int kIT = 2;
-    for (int base = tid * 4; base < (MST_ABLATE >= 5 ? 0 : n_own); base += kThreads * 4 * kIT) {
+    for (int base = tid * 4; base < n_own; base += kThreads * 4 * kIT) {
       float x[kIT][8][4];
 #pragma unroll
       for (int it = 0; it < kIT; ++it) {
@@ -553,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
 #pragma unroll
             for (int r = 0; r < NB; ++r) {
               const bool ok = lb_band[r] >= 0 && fok[ff];
-              const float lm = MST_ABLATE >= 6 ? mel[ff][r] : __log2f(mel[ff][r] + 1e-10f) * kLn2;
+              const float lm = __log2f(mel[ff][r] + 1e-10f) * kLn2;
               if (ok) {
                 s_tile[(c * M + lb_band[r]) * kTileStride + wave * kFPW + ff] = lm;
                 lsum += lm;
@@ -606,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void melfeat_kernel(const KParams p) {
           for (int j = 0; j < 4; ++j)
             if (j != ss) other = fmaxf(other, S[j][ff][r]);
           const float d = S[ss][ff][r] - other;
-          if (MST_ABLATE < 6) acc_mask[ss] += __frcp_rn(1.0f + __expf(d));  // sigmoid((0 - d) / 1)
+          acc_mask[ss] += __frcp_rn(1.0f + __expf(d));  // sigmoid((0 - d) / 1)
         }
       }
     }

@@ -100,14 +100,23 @@ def test_encoder_is_bit_identical_from_either_layout(cfgname, T, B, precision):
         e0, t0 = enc.forward(ref, feats, taps=True)
         e1, t1 = enc.forward(cm, feats, taps=True)
     torch.cuda.synchronize()
-    for k in ("film", "pool1", "pool_in"):
-        assert torch.equal(t0[k], t1[k]), k
-    assert torch.equal(e0, e1)
+    if precision == "fp32":   # same kernel arithmetic, same k order: bit for bit
+        for k in ("film", "pool1", "pool_in"):
+            assert torch.equal(t0[k], t1[k]), k
+        assert torch.equal(e0, e1)
+    else:   # the channel-minor f16 conv1 (conv1_f16e_kernel, bank-conflict-free) sums the SAME products -- the operands are the
+        #     same bits -- over the taps in another order: fp32 accumulation-order differences only
+        assert torch.equal(t0["film"], t1["film"])
+        for k, a, b in (("pool1", t0["pool1"], t1["pool1"]), ("pool_in", t0["pool_in"], t1["pool_in"]), ("emb", e0, e1)):
+            err = (a - b).abs().max().item() / b.abs().max().item()
+            # plain f16: conv2 reads pool1 ROUNDED to float16 -- a last-bit difference of conv1's sum can land on the neighbouring
+            # float16 (1e-3 of that element), which the later tensors inherit
+            assert err <= (2e-6 if precision != "f16" or k == "pool1" else 1e-3), (k, err)
     # the module's own forward negotiates the layout and fills the deferred features from the same launch
     from mst_amd.mixing_utils import deferred_features
     with torch.no_grad():
         e2 = m(d, torch.stack([deferred_features(64)] * B).cuda())
-    assert torch.equal(e2, e0)
+    assert torch.equal(e2, e1)
 
 
 def test_config5_geometry_from_channel_minor():
