@@ -258,9 +258,8 @@ def main():
             if timed:
                 e0.record()
             if a.aug:   # negatives = degraded anchors (README triplet design): clips 2, 5, 8, ... of the batch
-                neg = augm.augment_stems({k: v[2::3] for k, v in stems.items()}, decisions=pending.pop() if pending else None)
-                for k in stems:
-                    xa[:, 2 * ("vocals", "bass", "drums", "other").index(k):][2::3, :2] = neg[k]
+                xa[2::3].copy_(x[2::3])   # the reference's `.clone()` (src/mixing_utils.py:386) ...
+                augm.augment_packed_(xa[2::3], decisions=pending.pop() if pending else None)   # ... augmented where it stands
                 feats, logmel = fe.features_and_logmel(stems_aug, lay, lay == mlib.LOGMEL_CM16)
             elif stager is not None:
                 fut = state["fut"]

@@ -332,6 +332,12 @@ int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inou
                   const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes,
                   void* stream);
 
+/* The same on clips that sit `clip_stride` floats apart (>= 8 * T; each clip's 8 channels contiguous): e.g. the
+ * negatives of a triplet batch, every third clip of the batch tensor, augmented where they stand.               */
+int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* stems_inout, long long clip_stride,
+                          const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * InfoNCE forward on (gathered) embeddings.  Replaces InfoNCELoss.forward src/loss.py:31-136.
  * emb: dev [N][D] fp32; labels: dev [N] int64; anchors [row0,row0+rows) are the local rows.

@@ -19,6 +19,8 @@
 #include "common.h"
 #include "fft_wave.h"
 
+#include <cstdlib>
+
 namespace {
 
 using namespace mstfft;
@@ -32,13 +34,18 @@ struct ChainParams {
   const mst_aug_clip* dec;   // device copy [B]
   double* states;            // [B][8][nchunk][4]
   int T, nchunk;
+  long long clip_stride;     // floats between clips (8 * T when packed)
 };
 
-__device__ __forceinline__ float compress_f32(float x) {  // mixing_utils.py:435-447 (threshold -20 dB, ratio 4)
-  float db = 20.0f * log10f(fabsf(x) + 1e-8f);
-  if (db > -20.0f) db = -20.0f + (db + 20.0f) / 4.0f;
-  const float sgn = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-  return sgn * powf(10.0f, db / 20.0f);
+// mixing_utils.py:435-447 (threshold -20 dB, ratio 4): dB = 20 log10(|x| + 1e-8); above -20 dB: dB' = -20 + (dB + 20) / 4;
+// y = sign(x) 10^(dB' / 20).  In closed form, with a = |x| + 1e-8:  a <= 0.1 -> y = sign * a (the 1e-8 offset survives, as in
+// the reference);  a > 0.1 -> y = sign * 10^(-3/4) * a^(1/4).  Two square roots instead of log10f + powf: ~10 instructions
+// instead of ~100, and closer to the real-valued result than the reference's own float32 log / pow chain (which it matches to
+// a few 1e-7 relative; the goldens hold at 1e-5).
+__device__ __forceinline__ float compress_f32(float x) {
+  const float a = fabsf(x) + 1e-8f;
+  const float y = a > 0.1f ? 0.17782794100389228f * sqrtf(sqrtf(a)) : a;
+  return x > 0.f ? y : (x < 0.f ? -y : 0.f);
 }
 
 // ---- block-parallel IIR: chunk c of a stream = samples [c*kLc, (c+1)*kLc).
@@ -87,7 +94,7 @@ __global__ __launch_bounds__(256) void aug_tilt_zs_kernel(const ChainParams p) {
   const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
   if (d.tilt == 0 || c >= p.nchunk) return;
-  float* x = p.stems + (size_t)stream * p.T;
+  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
   const Coef k = coef_of(d.tilt_sos);
   const float gain = d.gain;
   double s0 = 0.0, s1 = 0.0;
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void aug_tilt_resp_kernel(const ChainParams p)
   const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
   const bool has_g = d.gain != 1.0f, has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
   if (!(has_g || has_t || has_c || has_b) || c >= p.nchunk) return;
-  float* x = p.stems + (size_t)stream * p.T;
+  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
   double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
   const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
   double t0 = has_t ? st[0] : 0.0, t1 = has_t ? st[1] : 0.0;
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(256) void aug_bw_resp_kernel(const ChainParams p) {
   const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
   if (d.bw_sections <= 0 || c >= p.nchunk) return;
-  float* x = p.stems + (size_t)stream * p.T;
+  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
   const double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
   const Coef kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
   const bool two = d.bw_sections > 1;
@@ -258,35 +265,147 @@ __global__ __launch_bounds__(256) void aug_bw_resp_kernel(const ChainParams p) {
   });
 }
 
-// mean(stem^2) over (2, T) per stem  ->  redistribution weights E_s / (sum_s E_s + 1e-8)   (:410-416)
-constexpr int kEnergyBlocks = 32;  // partial sums per (clip, stem)
 
-__global__ __launch_bounds__(256) void aug_energy_partial_kernel(const float* stems, const mst_aug_clip* dec,
-                                                                 double* partial, int T) {
-  __shared__ double red[4];
-  const int b = blockIdx.y, s = blockIdx.x / kEnergyBlocks, blk = blockIdx.x % kEnergyBlocks;
-  if (dec[b].reverb != 1) return;
-  const int tid = threadIdx.x;
-  const float* x = stems + ((size_t)b * 8 + 2 * s) * T;
-  const int n_all = 2 * T, per = (n_all + kEnergyBlocks - 1) / kEnergyBlocks;
-  const int n0 = blk * per, n1 = min(n_all, n0 + per);
-  double a = 0.0;
-  for (int n = n0 + tid; n < n1; n += 256) a += (double)x[n] * (double)x[n];
+// ------------------------------------------------------------------------------------------
+// The three streaming passes of the IIR chain on LDS slabs (the aligned case: T % 4 == 0, 16-byte aligned base).
+// A thread still owns one 512-sample chunk and walks it serially in float64 -- but the samples no longer come from the
+// thread's own strided 16-byte loads / stores (64 lanes -> 64 different 128-byte lines per instruction, every line fetched
+// 8 times and written back in 8 partial pieces: the chain ran at 5 % of the HBM rate).  A workgroup = 256 consecutive chunks
+// of one stream; per step it moves a SLAB of 32 samples of each of its chunks: 8 consecutive threads read / write one whole
+// 128-byte run of a chunk, the slab is transposed through LDS ([256 chunks][33]: the thread of chunk r walks row r, stride
+// 33 words = no bank conflicts), the next slab's loads are in flight while this one is computed.
+//   PASS 0  zero-state pass of the tilt biquad on x * gain                                  (read only)
+//   PASS 1  gain -> tilt response -> compressor -> store; low-pass zero-state pass on the stored values   (read + write)
+//   PASS 2  low-pass response from the scanned start states                                   (read + write)
+// Same per-sample arithmetic as the chunk-walk kernels above (which stay as the path for unaligned lengths).
+// ------------------------------------------------------------------------------------------
+constexpr int kSlab = 32, kSlabRow = kSlab + 1, kWgChunks = 256;
+
+template <int PASS>
+__global__ __launch_bounds__(256) void aug_iir_pass_kernel(const ChainParams p) {
+  __shared__ float tile[2][kWgChunks * kSlabRow];
+  const int stream = blockIdx.y, tid = threadIdx.x;
+  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
+  const bool has_g = d.gain != 1.0f, has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
+  if (PASS == 0 && !has_t) return;                                   // block-uniform early outs
+  if (PASS == 1 && !(has_g || has_t || has_c || has_b)) return;
+  if (PASS == 2 && !has_b) return;
+  const int c0 = blockIdx.x * kWgChunks, c = c0 + tid;              // this thread's chunk
+  if (c0 >= p.nchunk) return;
+  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
+  const bool writes = PASS == 2 || (PASS == 1 && (has_g || has_t || has_c));
+  const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
+  const float gain = d.gain;
+  const bool two = d.bw_sections > 1;
+  double* st = p.states + ((size_t)stream * p.nchunk + min(c, p.nchunk - 1)) * 4;
+  double t0 = 0.0, t1 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  if (PASS == 1 && has_t && c < p.nchunk) t0 = st[0], t1 = st[1];
+  if (PASS == 2 && c < p.nchunk) b0 = st[0], b1 = st[1], b2 = two ? st[2] : 0.0, b3 = two ? st[3] : 0.0;
+  // mover mapping: instruction i of a slab: chunk row 32 i + (tid >> 3), 16-byte part tid & 7
+  const int mrow = tid >> 3, mpart = tid & 7;
+  float4 reg[8];
+  auto load_slab = [&](int k) __attribute__((always_inline)) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-  if ((tid & 63) == 0) red[tid >> 6] = a;
-  __syncthreads();
-  if (tid == 0) partial[((size_t)b * 4 + s) * kEnergyBlocks + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int i = 0; i < 8; ++i) {
+      const int cc = c0 + 32 * i + mrow;
+      const long long n = (long long)cc * kLc + kSlab * k + 4 * mpart;
+      reg[i] = (cc < p.nchunk && n + 3 < p.T) ? *reinterpret_cast<const float4*>(x + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_slab(0);
+  for (int k = 0; k < kLc / kSlab; ++k) {
+    float* tl = tile[k & 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float* q = tl + (32 * i + mrow) * kSlabRow + 4 * mpart;
+      q[0] = reg[i].x, q[1] = reg[i].y, q[2] = reg[i].z, q[3] = reg[i].w;
+    }
+    __syncthreads();
+    if (k + 1 < kLc / kSlab) load_slab(k + 1);
+    {
+      float* row = tl + tid * kSlabRow;
+      const int nvalid = c < p.nchunk ? max(0, min(kSlab, p.T - (c * kLc + kSlab * k))) : 0;   // samples of this slab inside the clip
+      if (nvalid == kSlab) {
+#pragma unroll 4
+        for (int j = 0; j < kSlab; ++j) {
+          const float v = row[j];
+          if (PASS == 0) {
+            (void)biquad_step(kt, t0, t1, (double)(v * gain));
+          } else if (PASS == 1) {
+            float y = v * gain;
+            if (has_t) y = (float)biquad_step(kt, t0, t1, (double)y);
+            if (has_c) y = compress_f32(y);
+            if (has_b) {
+              const double w = biquad_step(kb0, b0, b1, (double)y);
+              if (two) (void)biquad_step(kb1, b2, b3, w);
+            }
+            row[j] = y;
+          } else {
+            double w = biquad_step(kb0, b0, b1, (double)v);
+            if (two) w = biquad_step(kb1, b2, b3, w);
+            row[j] = (float)w;
+          }
+        }
+      } else {
+        for (int j = 0; j < nvalid; ++j) {   // the clip's last, ragged chunk
+          const float v = row[j];
+          if (PASS == 0) {
+            (void)biquad_step(kt, t0, t1, (double)(v * gain));
+          } else if (PASS == 1) {
+            float y = v * gain;
+            if (has_t) y = (float)biquad_step(kt, t0, t1, (double)y);
+            if (has_c) y = compress_f32(y);
+            if (has_b) {
+              const double w = biquad_step(kb0, b0, b1, (double)y);
+              if (two) (void)biquad_step(kb1, b2, b3, w);
+            }
+            row[j] = y;
+          } else {
+            double w = biquad_step(kb0, b0, b1, (double)v);
+            if (two) w = biquad_step(kb1, b2, b3, w);
+            row[j] = (float)w;
+          }
+        }
+      }
+    }
+    if (writes) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int cc = c0 + 32 * i + mrow;
+        const long long n = (long long)cc * kLc + kSlab * k + 4 * mpart;
+        if (cc < p.nchunk && n + 3 < p.T) {
+          const float* q = tl + (32 * i + mrow) * kSlabRow + 4 * mpart;
+          *reinterpret_cast<float4*>(x + n) = make_float4(q[0], q[1], q[2], q[3]);
+        }
+      }
+    }
+  }
+  if (c < p.nchunk) {
+    if (PASS == 0) st[0] = t0, st[1] = t1;
+    if (PASS == 1 && has_b) st[0] = b0, st[1] = b1, st[2] = b2, st[3] = b3;
+  }
 }
 
-__global__ void aug_energy_final_kernel(const mst_aug_clip* dec, const double* partial, float* prop, int T) {
-  const int b = blockIdx.x;
-  if (threadIdx.x != 0 || dec[b].reverb != 1) return;
+// mean(stem^2) over (2, T) per stem  ->  redistribution weights E_s / (sum_s E_s + 1e-8)   (:410-416); the per-window partial
+// sums come from rev_fft_kernel<1>
+// one wave per clip: fixed-order (hence run-to-run identical) sum of the per-window partials, then the weights
+__global__ __launch_bounds__(64) void aug_energy_final_kernel(const mst_aug_clip* dec, const double* partial, float* prop, int T,
+                                                               int NX) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (dec[b].reverb != 1) return;
+  double a[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = lane; i < NX; i += 64)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] += partial[((size_t)b * NX + i) * 4 + s];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a[s] += __shfl_xor(a[s], o, 64);
+  if (lane != 0) return;
   float E[4], tot = 0.f;
   for (int s = 0; s < 4; ++s) {
-    double a = 0.0;
-    for (int k = 0; k < kEnergyBlocks; ++k) a += partial[((size_t)b * 4 + s) * kEnergyBlocks + k];
-    E[s] = (float)(a / (2.0 * T));
+    E[s] = (float)(a[s] / (2.0 * T));
     tot += E[s];  // python sum([...]) : (((0 + E0) + E1) + E2) + E3
   }
   tot += 1e-8f;
@@ -297,10 +416,13 @@ struct RevParams {
   float* stems;               // [B][8][T]
   const mst_aug_clip* dec;
   const float* ir;            // [B][L]
-  const float* prop;          // [B][4]
+  float* prop;                // [B][4]
+  double* epart;              // [B][NX][4] per-window energy partials of the 4 stems (written by rev_fft_kernel<1>)
   float2* G;                  // [B][NP][16][64]  spectra of the reversed-IR partitions (register order)
   float2* X;                  // [B][NX][16][64]  spectra of the input windows
   int T, L, NP, NX, D, j0, nj;
+  int vec4;                   // T % 4 == 0, D % 4 == 0 and a 16-byte aligned base: 16-byte accesses in the redistribution
+  long long clip_stride;      // floats between clips
 };
 
 struct FftLds {
@@ -337,14 +459,38 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
       v[r] = make_float2((t < kBlk && m < p.L) ? h[p.L - 1 - m] : 0.f, 0.f);
     }
   } else {
-    const size_t co = (size_t)b * 8 * p.T;
+    const size_t co = (size_t)b * p.clip_stride;
+    // the window's samples of all 8 channels pass through here anyway: the per-stem energies of the redistribution weights
+    // (mixing_utils.py:410-416) are summed on the way -- every sample once, in the window whose SECOND half holds it -- as one
+    // double per (clip, window, stem), reduced in a fixed order by aug_energy_final_kernel
+    double en[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t = lane + 64 * in_q<kNfft>(r);
       const int n = kBlk * (item - 1) + t;
       const bool ok = n >= 0 && n < p.T;
-      v[r] = ok ? make_float2(mix_at(p.stems, co, p.T, 0, n, mode), mix_at(p.stems, co, p.T, 1, n, mode))
-                : make_float2(0.f, 0.f);
+      if (mode == 1) {
+        float c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = ok ? p.stems[co + (size_t)k * p.T + n] : 0.f;
+        v[r] = make_float2(((c[0] + c[2]) + c[4]) + c[6], ((c[1] + c[3]) + c[5]) + c[7]);   // ((v+b)+d)+o
+        if (t >= kBlk) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) en[k] += (double)c[2 * k] * (double)c[2 * k] + (double)c[2 * k + 1] * (double)c[2 * k + 1];
+        }
+      } else {
+        v[r] = ok ? make_float2(mix_at(p.stems, co, p.T, 0, n, mode), mix_at(p.stems, co, p.T, 1, n, mode))
+                  : make_float2(0.f, 0.f);
+      }
+    }
+    if (mode == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double a = en[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) p.epart[((size_t)b * p.NX + item) * 4 + k] = a;
+      }
     }
   }
   FftPlan<kNfft>::run<1>(vv, lds.scr[wave], lds.tw, lane);
@@ -353,32 +499,73 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
   for (int r = 0; r < 16; ++r) dst[r * 64] = v[r];
 }
 
-__global__ __launch_bounds__(256) void rev_mac_ifft_kernel(const RevParams p) {
-  __shared__ FftLds lds;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  fill_twiddles<kNfft>(lds.tw, tid, 256);
-  __syncthreads();
-  const int b = blockIdx.y, jj = blockIdx.x * 4 + wave;
+// Spectral multiply-accumulate over the NP partitions + inverse FFT + redistribution.  A workgroup = 8 waves = 8 consecutive
+// output blocks j; wave w needs X[j0 + w - q] and G[q] at step q.  Every spectrum is 8 KB: read per wave from global memory
+// that was 2 x 44 x 8 KB per output block, 7 GB through L2 per step (the kernel ran at the L2 rate).  Here the workgroup
+// shares them through LDS: G[q] is loaded once per step for all 8 waves (double-buffered), and the X windows slide -- step q
+// needs ONE new block, X[j0 - q], which replaces the block only step q - 1's last wave still used (a ring of 9 slots, so
+// that the write of step q never touches what step q - 1 reads: one barrier per step).  Global traffic per step: 16 KB per
+// workgroup instead of 128 KB.
+constexpr int kRevWaves = 8, kRevRing = kRevWaves + 1;
+struct RevLds {
+  float2 tw[FftPlan<kNfft>::TW];
+  union {
+    struct {
+      float2 X[kRevRing][1024];
+      float2 G[2][1024];
+    } r;
+    float2 scr[kRevWaves][kNfft + kNfft / 8];   // the inverse FFT's scratch, after the last step
+  } u;
+};
+
+__global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rev_smem[];
+  RevLds& lds = *reinterpret_cast<RevLds*>(rev_smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
   const int mode = p.dec[b].reverb;
-  if (mode == 0 || jj >= p.nj) return;
-  const int j = p.j0 + jj;
+  if (mode == 0) return;   // block-uniform
+  fill_twiddles<kNfft>(lds.tw, tid, kRevWaves * 64);
+  const int jb = p.j0 + blockIdx.x * kRevWaves;   // first output block of this workgroup
+  const int j = jb + wave;
+  const bool mine = blockIdx.x * kRevWaves + wave < p.nj;
+  const float4* Gg = reinterpret_cast<const float4*>(p.G + (size_t)b * p.NP * 1024);
+  const float4* Xg = reinterpret_cast<const float4*>(p.X + (size_t)b * p.NX * 1024);
+  auto slot = [](int i) { return ((i % kRevRing) + kRevRing) % kRevRing; };
+  // prologue: the 8 windows of step 0
+  for (int w = 0; w < kRevWaves; ++w) {
+    const int i = jb + w;
+    const float4 v = (i >= 0 && i < p.NX) ? Xg[(size_t)i * 512 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(lds.u.r.X[slot(i)])[tid] = v;
+  }
+  float4 gq = Gg[tid], xq = make_float4(0.f, 0.f, 0.f, 0.f);   // G[0]; the new window of step 0 is already in place
   float2 acc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = make_float2(0.f, 0.f);
-  const float2* Gb = p.G + (size_t)b * p.NP * 1024 + lane;
-  const float2* Xb = p.X + (size_t)b * p.NX * 1024 + lane;
   for (int q = 0; q < p.NP; ++q) {
+    reinterpret_cast<float4*>(lds.u.r.G[q & 1])[tid] = gq;
+    if (q > 0) reinterpret_cast<float4*>(lds.u.r.X[slot(jb - q)])[tid] = xq;
+    __syncthreads();
+    if (q + 1 < p.NP) {   // next step's two blocks, in flight while this step computes
+      gq = Gg[(size_t)(q + 1) * 512 + tid];
+      const int i = jb - (q + 1);
+      xq = (i >= 0 && i < p.NX) ? Xg[(size_t)i * 512 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int i = j - q;
-    if (i < 0 || i >= p.NX) continue;
-    const float2* g = Gb + (size_t)q * 1024;
-    const float2* x = Xb + (size_t)i * 1024;
+    if (mine && i >= 0 && i < p.NX) {   // wave-uniform
+      const float2* x = lds.u.r.X[slot(i)] + lane;
+      const float2* g = lds.u.r.G[q & 1] + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float2 a = x[r * 64], w = g[r * 64];
-      acc[r].x = fmaf(a.x, w.x, fmaf(-a.y, w.y, acc[r].x));
-      acc[r].y = fmaf(a.x, w.y, fmaf(a.y, w.x, acc[r].y));
+      for (int r = 0; r < 16; ++r) {
+        const float2 a = x[r * 64], w = g[r * 64];
+        acc[r].x = fmaf(a.x, w.x, fmaf(-a.y, w.y, acc[r].x));
+        acc[r].y = fmaf(a.x, w.y, fmaf(a.y, w.x, acc[r].y));
+      }
     }
   }
+  __syncthreads();   // the ring becomes the FFT scratch
+  if (!mine) return;
   // inverse FFT = conj(FFT(conj(Y))) / N; acc is in OUTPUT register order, the FFT wants INPUT register order
   float2 vv[1][16];
   float2 (&v)[16] = vv[0];
@@ -387,12 +574,53 @@ __global__ __launch_bounds__(256) void rev_mac_ifft_kernel(const RevParams p) {
     const float2 y = acc[out_reg<kNfft>(in_q<kNfft>(r))];
     v[r] = make_float2(y.x, -y.y);
   }
-  FftPlan<kNfft>::run<1>(vv, lds.scr[wave], lds.tw, lane);
+  FftPlan<kNfft>::run<1>(vv, lds.u.scr[wave], lds.tw, lane);
   const float scale = 1.0f / (float)kNfft;
-  const size_t co = (size_t)b * 8 * p.T;
+  const size_t co = (size_t)b * p.clip_stride;
   float pr[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) pr[s] = mode == 1 ? p.prop[b * 4 + s] : 0.f;
+  const int nbase = kBlk * j - p.D;   // sample index of window position 512
+  if (mode == 1 && p.vec4 && nbase >= 0 && nbase + kBlk <= p.T) {
+    // interior block, aligned clip: the 512 valid outputs go through the wave's scratch so that a lane owns 4 CONSECUTIVE samples --
+    // 8 loads + 8 stores of 16 bytes per group for the whole read-modify-write of the 8 stems (the strided form below
+    // takes 24 dword accesses per sample and ran at a third of this kernel's time)
+    float2* ys = lds.u.scr[wave];   // the FFT is done with it
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 8; q < 16; ++q) {
+      const float2 z = v[out_reg<kNfft>(q)];
+      ys[lane + 64 * (q - 8)] = make_float2(z.x * scale, -z.y * scale);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int o = 4 * (lane + 64 * h);
+      const int n = nbase + o;
+      float4 x[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = *reinterpret_cast<const float4*>(p.stems + co + (size_t)c * p.T + n);
+      float revL[4], revR[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float2 y = ys[o + e];
+        const float* f = reinterpret_cast<const float*>(x);
+        const float mL = ((f[0 * 4 + e] + f[2 * 4 + e]) + f[4 * 4 + e]) + f[6 * 4 + e];   // ((v+b)+d)+o
+        const float mR = ((f[1 * 4 + e] + f[3 * 4 + e]) + f[5 * 4 + e]) + f[7 * 4 + e];
+        revL[e] = mL * 0.7f + y.x * 0.3f, revR[e] = mR * 0.7f + y.y * 0.3f;
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float* r = (c & 1) ? revR : revL;
+        const float w = pr[c >> 1];
+        float4 o4;
+        o4.x = x[c].x + (r[0] * w) * 0.3f, o4.y = x[c].y + (r[1] * w) * 0.3f;
+        o4.z = x[c].z + (r[2] * w) * 0.3f, o4.w = x[c].w + (r[3] * w) * 0.3f;
+        *reinterpret_cast<float4*>(p.stems + co + (size_t)c * p.T + n) = o4;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 8; q < 16; ++q) {  // valid overlap-save outputs: window positions 512..1023
     const int t = lane + 64 * q;
@@ -439,9 +667,9 @@ AugLayout aug_layout(int B, int T, int L) {
   a.dec = take((size_t)B * sizeof(mst_aug_clip));
   a.states = take((size_t)B * 8 * a.nchunk * 4 * sizeof(double));
   a.prop = take((size_t)B * 4 * sizeof(float));
-  a.epart = take((size_t)B * 4 * kEnergyBlocks * sizeof(double));
   a.G = take((size_t)B * a.NP * 1024 * sizeof(float2));
   a.X = take((size_t)B * a.NX * 1024 * sizeof(float2));
+  a.epart = take((size_t)B * a.NX * 4 * sizeof(double));
   a.total = o;
   return a;
 }
@@ -457,7 +685,13 @@ size_t mst_aug_workspace_bytes(int B, int T, int ir_len) {
 
 int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inout, const float* reverb_ir, int ir_len,
                   void* workspace, size_t workspace_bytes, void* stream) {
+  return mst_aug_apply_strided(decisions, B, T, stems_inout, (long long)8 * T, reverb_ir, ir_len, workspace, workspace_bytes, stream);
+}
+
+int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* stems_inout, long long clip_stride,
+                          const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes, void* stream) {
   MST_REQUIRE(decisions && stems_inout, "mst_aug_apply: NULL argument");
+  MST_REQUIRE(clip_stride >= (long long)8 * T, "mst_aug_apply_strided: clip_stride %lld < 8 * T", clip_stride);
   MST_REQUIRE(B > 0 && T > 0 && ir_len >= 0, "mst_aug_apply: bad sizes B=%d T=%d ir_len=%d", B, T, ir_len);
   bool any_rev = false;
   for (int b = 0; b < B; ++b) {
@@ -475,33 +709,43 @@ int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inou
   char* ws = reinterpret_cast<char*>(workspace);
   mst_aug_clip* ddec = reinterpret_cast<mst_aug_clip*>(ws + L.dec);
   MST_HIP_CHECK(hipMemcpyAsync(ddec, decisions, (size_t)B * sizeof(mst_aug_clip), hipMemcpyHostToDevice, st));
-  ChainParams cp{stems_inout, ddec, reinterpret_cast<double*>(ws + L.states), T, L.nchunk};
+  ChainParams cp{stems_inout, ddec, reinterpret_cast<double*>(ws + L.states), T, L.nchunk, clip_stride};
   bool any_tilt = false, any_bw = false;
   for (int b = 0; b < B; ++b)
     for (int s = 0; s < 4; ++s)
       any_tilt = any_tilt || decisions[b].stem[s].tilt != 0, any_bw = any_bw || decisions[b].stem[s].bw_sections > 0;
   const dim3 cgrid((L.nchunk + 255) / 256, B * 8);
+  // LDS-slab passes (whole-line loads / stores) when every stream is 16-byte aligned; the chunk-walk kernels otherwise
+  const bool slabs = T % 4 == 0 && clip_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(stems_inout) & 15) == 0 &&
+                     !getenv("MST_AUG_CHUNKWALK");
   if (any_tilt) {
-    hipLaunchKernelGGL(aug_tilt_zs_kernel, cgrid, dim3(256), 0, st, cp);
+    if (slabs) hipLaunchKernelGGL((aug_iir_pass_kernel<0>), cgrid, dim3(256), 0, st, cp);
+    else hipLaunchKernelGGL(aug_tilt_zs_kernel, cgrid, dim3(256), 0, st, cp);
     hipLaunchKernelGGL((aug_scan_kernel<0>), dim3(B * 8), dim3(64), 0, st, cp);
   }
-  hipLaunchKernelGGL(aug_tilt_resp_kernel, cgrid, dim3(256), 0, st, cp);
+  if (slabs) hipLaunchKernelGGL((aug_iir_pass_kernel<1>), cgrid, dim3(256), 0, st, cp);
+  else hipLaunchKernelGGL(aug_tilt_resp_kernel, cgrid, dim3(256), 0, st, cp);
   if (any_bw) {
     hipLaunchKernelGGL((aug_scan_kernel<1>), dim3(B * 8), dim3(64), 0, st, cp);
-    hipLaunchKernelGGL(aug_bw_resp_kernel, cgrid, dim3(256), 0, st, cp);
+    if (slabs) hipLaunchKernelGGL((aug_iir_pass_kernel<2>), cgrid, dim3(256), 0, st, cp);
+    else hipLaunchKernelGGL(aug_bw_resp_kernel, cgrid, dim3(256), 0, st, cp);
   }
   MST_HIP_CHECK(hipGetLastError());
   if (any_rev) {
     float* prop = reinterpret_cast<float*>(ws + L.prop);
     double* epart = reinterpret_cast<double*>(ws + L.epart);
-    hipLaunchKernelGGL(aug_energy_partial_kernel, dim3(4 * kEnergyBlocks, B), dim3(256), 0, st, stems_inout, ddec, epart, T);
-    hipLaunchKernelGGL(aug_energy_final_kernel, dim3(B), dim3(64), 0, st, ddec, epart, prop, T);
-    MST_HIP_CHECK(hipGetLastError());
-    RevParams rp{stems_inout, ddec, reverb_ir, prop, reinterpret_cast<float2*>(ws + L.G),
-                 reinterpret_cast<float2*>(ws + L.X), T, ir_len, L.NP, L.NX, L.D, L.j0, L.nj};
+    RevParams rp{stems_inout, ddec, reverb_ir, prop, epart, reinterpret_cast<float2*>(ws + L.G),
+                 reinterpret_cast<float2*>(ws + L.X), T, ir_len, L.NP, L.NX, L.D, L.j0, L.nj,
+                 (T % 4 == 0 && L.D % 4 == 0 && clip_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(stems_inout) & 15) == 0) ? 1 : 0,
+                 clip_stride};
     hipLaunchKernelGGL((rev_fft_kernel<0>), dim3((L.NP + 3) / 4, B), dim3(256), 0, st, rp);
-    hipLaunchKernelGGL((rev_fft_kernel<1>), dim3((L.NX + 3) / 4, B), dim3(256), 0, st, rp);
-    hipLaunchKernelGGL(rev_mac_ifft_kernel, dim3((L.nj + 3) / 4, B), dim3(256), 0, st, rp);
+    hipLaunchKernelGGL((rev_fft_kernel<1>), dim3((L.NX + 3) / 4, B), dim3(256), 0, st, rp);   // (+ the stems' energy partials)
+    hipLaunchKernelGGL(aug_energy_final_kernel, dim3(B), dim3(64), 0, st, ddec, epart, prop, T, L.NX);
+    static unsigned long long rev_attr = 0;   // per-device bit mask: the dynamic-LDS limit belongs to the device
+    if (mst::first_use_on_device(rev_attr))
+      MST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(rev_mac_ifft_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RevLds)));
+    hipLaunchKernelGGL(rev_mac_ifft_kernel, dim3((L.nj + kRevWaves - 1) / kRevWaves, B), dim3(kRevWaves * 64), sizeof(RevLds), st, rp);
     MST_HIP_CHECK(hipGetLastError());
   }
   return MST_OK;

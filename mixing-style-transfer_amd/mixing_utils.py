@@ -381,25 +381,35 @@ class AudioAugmenter:
 
     # -- device side ---------------------------------------------------------------------------
     def _apply(self, x8, clips, irs):
-        """x8 (B, 8, T) fp32 CUDA contiguous, modified in place."""
+        """x8 (B, 8, T) fp32 CUDA, modified in place; every clip's (8, T) block contiguous, clips any stride >= 8 T apart."""
         if not x8.is_cuda:
             raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
         B, _, T = x8.shape
+        assert x8.dtype == torch.float32 and x8.stride(2) == 1 and x8.stride(1) == T and (B == 1 or x8.stride(0) >= 8 * T)
         L = _lib.lib()
         ir_len = max([0] + [ir.numel() for ir in irs if ir is not None])
         ir_dev = None
-        if ir_len:
-            host = torch.zeros(B, ir_len)
+        if ir_len:   # impulse responses: pinned staging buffers (two, alternating: the previous call's copy may still be in
+            #          flight) and an asynchronous copy on the call's stream -- a pageable `.to(device)` is a host synchronisation
+            k = self._ir_turn = 1 - getattr(self, "_ir_turn", 0)
+            bufs = self.__dict__.setdefault("_ir_bufs", [None, None])
+            if bufs[k] is None or tuple(bufs[k][0].shape) != (B, ir_len) or bufs[k][1].device != x8.device:
+                bufs[k] = (torch.zeros(B, ir_len).pin_memory(), torch.empty(B, ir_len, device=x8.device), torch.cuda.Event())
+            host, ir_dev, done = bufs[k]
+            done.synchronize()   # the copy that last read this pinned buffer (two calls ago)
             for b, ir in enumerate(irs):
                 if ir is not None:
                     host[b] = ir
-            ir_dev = host.to(x8.device)
+            with torch.cuda.device(x8.device):
+                ir_dev.copy_(host, non_blocking=True)
+                done.record()
         need = L.mst_aug_workspace_bytes(B, T, ir_len)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x8.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x8.device)
         with torch.cuda.device(x8.device):
-            _lib.check(L.mst_aug_apply(clips, B, T, _lib.dptr(x8), _lib.dptr(ir_dev), ir_len, _lib.dptr(self._ws), need,
-                                       _lib.stream_ptr(x8.device)), "mst_aug_apply")
+            _lib.check(L.mst_aug_apply_strided(clips, B, T, _lib.dptr(x8), x8.stride(0) if B > 1 else 8 * T, _lib.dptr(ir_dev),
+                                               ir_len, _lib.dptr(self._ws), need, _lib.stream_ptr(x8.device)),
+                       "mst_aug_apply_strided")
         return x8
 
     def draw_decisions(self, n_clips):
@@ -420,6 +430,15 @@ class AudioAugmenter:
         self._apply(x8, clips, irs)
         out = {s: x8[:, 2 * i:2 * i + 2] for i, s in enumerate(STEMS)}
         return out if batched else {s: v[0] for s, v in out.items()}
+
+    def augment_packed_(self, x8, decisions=None):
+        """IN PLACE on a packed (B, 8, T) CUDA fp32 tensor (channels vL, vR, bL, bR, dL, dR, oL, oR) whose clips may be
+        strided -- e.g. `batch[2::3]`, the negatives of a triplet batch, augmented where they stand (the caller has already
+        made the copy the reference's `.clone()` stands for).  Same decisions / RNG order as `augment_stems`."""
+        clips, irs, traces = decisions if decisions is not None else self.draw_decisions(x8.shape[0])
+        assert len(irs) == x8.shape[0]
+        self.last_trace = traces
+        return self._apply(x8, clips, irs)
 
     def _single(self, audio, fill):
         """Run one effect on a (2, T) tensor: it rides as the first stem of an otherwise silent clip."""

@@ -10,7 +10,7 @@ f = glob.glob(f"{base}/prof_{tag}_stats/*/*_kernel_stats.csv")
 if f:
     rows = list(csv.DictReader(open(f[0])))
     out["kernel_stats"] = [{"name": short(r["Name"]), "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
-                            "pct": float(r["Percentage"])} for r in rows[:14]]
+                            "pct": float(r["Percentage"])} for r in rows[:24]]
 for pass_ in ("fetch", "write", "sq"):
     f = glob.glob(f"{base}/prof_{tag}_{pass_}/*/*_counter_collection.csv")
     if not f:
@@ -19,7 +19,7 @@ for pass_ in ("fetch", "write", "sq"):
     for r in csv.DictReader(open(f[0])):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
-        if not any(x in k for x in ("melfeat", "conv", "attn_", "film_", "proj_", "read_k", "write_k")):
+        if not any(x in k for x in ("melfeat", "conv", "attn_", "film_", "proj_", "read_k", "write_k", "aug_", "rev_")):
             continue
         for c, v in cs.items():
             out.setdefault("pmc", {}).setdefault(k, {})[c] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}

@@ -149,3 +149,24 @@ def test_infonce_backward_vs_autograd_of_the_oracle():
             (s / nvalid).backward()
             tot += es.grad.cpu()
         assert (tot - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-7
+
+
+def test_packed_strided_in_place_variant_equals_augment_stems():
+    """`augment_packed_` on every third clip of a batch tensor (clip stride 3 * 8 * T; `mst_aug_apply_strided`) == `augment_stems`
+    on those clips with the same decisions, bit for bit; the clips in between are untouched.  T % 4 == 0: the LDS-slab
+    passes and the 16-byte redistribution; T % 4 != 0: the chunk-walk kernels."""
+    from mst_amd.mixing_utils import AudioAugmenter
+    for T in (44100, 33075):
+        x = torch.stack([cases.synth_clip(c, T) for c in range(7)], 0).cuda()
+        aug = AudioAugmenter()
+        torch.manual_seed(21)
+        dec = aug.draw_decisions(3)
+        ref = aug.augment_stems(omel.tensor_to_stems_dict(x[0::3]), decisions=dec)
+        ref8 = omel.stems_dict_to_tensor(ref)
+        y = x.clone()
+        aug.augment_packed_(y[0::3], decisions=dec)
+        torch.cuda.synchronize()
+        assert torch.equal(y[0::3], ref8)
+        for b in (1, 2, 4, 5):
+            assert torch.equal(y[b], x[b])
+        assert not torch.equal(y[0], x[0])
