@@ -219,6 +219,12 @@ typedef struct mst_encoder_train_taps {
    * (phase 0 normalises by B).                                                                                            */
   int phase;
   double count_scale;
+  /* Dropout drawn BY the kernel (instead of drop1_mask): with drop1_mask_out != NULL and 0 < drop1_p < 1 the first-pooling
+   * epilogue keeps element o iff philox2x32-10(drop1_seed, o) >= drop1_p * 2^32, scales the kept ones by 1 / (1 - p) and
+   * writes the keep-mask (uint8, layout of pool1) to drop1_mask_out -- pass that buffer to mst_encoder_train_conv2_dgrad.  */
+  unsigned char* drop1_mask_out;
+  uint64_t drop1_seed;
+  float drop1_p;
 } mst_encoder_train_taps;
 size_t mst_encoder_train_workspace_bytes(const mst_encoder* enc, int B, int frames);
 /* Where the statistics accumulators of conv layer 1 or 2 sit inside the training workspace: byte offset and number of

@@ -56,7 +56,8 @@ class LogmelIn(C.Structure):
 class EncoderTrainTaps(C.Structure):
     _fields_ = [("film", C.c_void_p), ("pool1", C.c_void_p), ("pool_in", C.c_void_p), ("bn1", C.c_void_p),
                 ("bn2", C.c_void_p), ("film_in", C.c_void_p), ("drop1_mask", C.c_void_p), ("drop1_scale", C.c_float),
-                ("phase", C.c_int), ("count_scale", C.c_double)]
+                ("phase", C.c_int), ("count_scale", C.c_double), ("drop1_mask_out", C.c_void_p), ("drop1_seed", C.c_uint64),
+                ("drop1_p", C.c_float)]
 
 
 class AugStem(C.Structure):

@@ -1994,7 +1994,30 @@ struct ApplyParams {
   _Float16* out_l16;        // split-precision training forward: the low part (v * s - hi) next to out_h16
   int pool_h;               // layer 1 on 2 x 40 tiles: 1 = MaxPool2d((1, 5)) (16-mel sub-bands: two 1 x 5 windows per 2 x 5 block), else (2, 5)
   const float* y_scale;     // non-NULL: yraw holds float16 times y_scale[band][0] (ConvParams::yraw16)
+  // Dropout drawn IN the kernel (layer 1): element o is kept iff philox(seed, o) >= drop_thresh (= p * 2^32); the keep-mask is
+  // written to mask_out (same layout as `out`) for the backward pass.  mask_out == NULL: the caller's `mask` (or none).
+  unsigned char* mask_out;
+  unsigned long long seed;
+  unsigned drop_thresh;
 };
+
+// Philox-2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter-based, so every element's draw is a
+// pure function of (seed, element index) -- no generator state, no order dependence, reproducible for a given seed.
+__device__ __forceinline__ uint2 philox2x32(unsigned c0, unsigned c1, unsigned key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
+    c0 = hi ^ key ^ c1;
+    c1 = lo;
+    key += 0x9E3779B9u;
+  }
+  return make_uint2(c0, c1);
+}
+// keep decision of element o (its pair partner o ^ 1 shares the block: callers with both may reuse it)
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t o, unsigned thresh) {
+  const uint2 r = philox2x32((unsigned)(o >> 1), (unsigned)(o >> 33) ^ (unsigned)(seed >> 32), (unsigned)seed);
+  return ((o & 1) ? r.y : r.x) >= thresh;
+}
 
 template <int LAYER, int SUB>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
@@ -2053,7 +2076,14 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
       const int prow = nh == 1 ? tr : 2 * tr + hr;
       if (pc < p.out_cols && prow < p.out_rows) {
         const size_t o = ((((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows + prow) * p.out_cols + pc;
-        const float v = p.mask ? (p.mask[o] ? m * p.mask_scale : 0.f) : m;
+        bool keep = true;
+        if (p.mask_out) {   // kernel-uniform: draw here, remember for the backward pass
+          keep = dropout_keep(p.seed, o, p.drop_thresh);
+          p.mask_out[o] = keep ? 1 : 0;
+        } else if (p.mask) {
+          keep = p.mask[o] != 0;
+        }
+        const float v = (p.mask_out || p.mask) ? (keep ? m * p.mask_scale : 0.f) : m;
         p.out[o] = v;
         if (p.out_h16) {
           const size_t o16 = ((((size_t)clip * p.nsub + band) * p.out_rows + prow) * p.out_cols + pc) * 32 + ch;
@@ -3457,12 +3487,19 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
       unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);   // (computed in front of conv1)
       float* fsc = reinterpret_cast<float*>(ws + T.t_f16scale);
       hipLaunchKernelGGL(f16_scale_band_kernel, dim3(ns), dim3(64), 0, st, aff1, e->w1norm, xmax, e->c1b,
-                         (taps && taps->drop1_mask) ? taps->drop1_scale : 1.f, fsc, B, ns);
+                         (taps && taps->drop1_mask_out && taps->drop1_p > 0.f) ? 1.f / (1.f - taps->drop1_p)
+                         : ((taps && taps->drop1_mask) ? taps->drop1_scale : 1.f), fsc, B, ns);
       ap.out_h16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_h16), ap.f16_scale = fsc;
       if (e->train_f16 == 2) ap.out_l16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_l16);
       if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys1);
     }
     ap.pool_h = e->sub;   // 2 x 40 tiles with 16-mel sub-bands (f16 modes): MaxPool2d((1, 5))
+    if (taps && taps->drop1_mask_out && taps->drop1_p > 0.f) {   // Dropout drawn in the kernel
+      MST_REQUIRE(taps->drop1_p < 1.f, "mst_encoder_forward_train: drop1_p must be in [0, 1)");
+      ap.mask_out = taps->drop1_mask_out, ap.seed = taps->drop1_seed;
+      ap.drop_thresh = (unsigned)std::min(4294967295.0, (double)taps->drop1_p * 4294967296.0);
+      ap.mask = nullptr, ap.mask_scale = 1.f / (1.f - taps->drop1_p);
+    }
     if (e->sub == 2 || train_fwd16(e)) hipLaunchKernelGGL((apply_kernel<1, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     else hipLaunchKernelGGL((apply_kernel<1, 1>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());

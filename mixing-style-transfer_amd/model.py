@@ -243,10 +243,11 @@ class HipEncoder:
         _lib.check(_lib.lib().mst_encoder_train_scale_buffer(self._h, B, frames, C.byref(off)), "mst_encoder_train_scale_buffer")
         return self._ws_view(off.value, 4, torch.int32)
 
-    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, sync=None):
+    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, sync=None, drop1_seed=None):
         """`forward_train_steps` run to completion; `sync` (an object with `.world`, `.sum(int64 tensor)`, `.max(int32 tensor)`,
         e.g. DistSync) adds the ranks' BatchNorm statistics between the phases; None = this process only."""
-        steps = self.forward_train_steps(logmel, feats, film, head, drop1_mask, drop1_p, sync.world if sync is not None else 0)
+        steps = self.forward_train_steps(logmel, feats, film, head, drop1_mask, drop1_p, sync.world if sync is not None else 0,
+                                         drop1_seed)
         try:
             while True:
                 kind, view = next(steps)
@@ -254,7 +255,8 @@ class HipEncoder:
         except StopIteration as done:
             return done.value
 
-    def forward_train_steps(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, world=0):
+    def forward_train_steps(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, world=0,
+                            drop1_seed=None):
         """Generator form of the train-mode forward.  world = 0: one call of `mst_encoder_forward_train`, nothing is yielded.
         world >= 1: the three phases of include/mst.h; after phase 1 and 2 it yields ("sum", int64 view of that layer's
         statistics accumulators), which the caller must all-reduce (SUM) over its `world` ranks before resuming.
@@ -262,7 +264,8 @@ class HipEncoder:
         Train-mode forward in libmst.so (`mst_encoder_forward_train`): BatchNorm with batch statistics.
         feats (B, Fd): FiLM MLP in HIP; or film (B, n_sub*192): FiLM parameters from the caller's own MLP.
         head=False stops at pool_in (emb is None).  drop1_mask: uint8 keep-mask shaped like pool1 (Dropout after the
-        first pooling).  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
+        first pooling); or drop1_seed (int) with drop1_p > 0: the kernel draws the mask itself (Philox, a pure function of
+        (seed, element)) and returns it as taps["drop1_mask"].  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
         1/sqrt(biased var + eps)).  The raw conv outputs stay in the workspace for `backward_apply`."""
         B, _, M, Fr = logmel.shape
         L = _lib.lib()
@@ -285,11 +288,16 @@ class HipEncoder:
         mask_c = drop1_mask.contiguous() if drop1_mask is not None else None
         if mask_c is not None:
             assert mask_c.dtype == torch.uint8 and tuple(mask_c.shape) == tuple(out["pool1"].shape)
+        mask_out = None
+        if drop1_seed is not None and drop1_p > 0.0:
+            assert mask_c is None, "pass a mask OR a seed"
+            mask_out = out["drop1_mask"] = torch.empty(out["pool1"].shape, dtype=torch.uint8, device=dev)
         lm = logmel.contiguous().float()
         for phase in ((0,) if world == 0 else (1, 2, 3)):
             t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")],
                                       _lib.dptr(film_c), _lib.dptr(mask_c), 1.0 / (1.0 - drop1_p) if mask_c is not None else 1.0,
-                                      phase, float(max(world, 1)))
+                                      phase, float(max(world, 1)), _lib.dptr(mask_out), int(drop1_seed or 0) & (2 ** 64 - 1),
+                                      float(drop1_p) if mask_out is not None else 0.0)
             with torch.cuda.device(dev):
                 _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(lm), Fr, _lib.dptr(feats_c), B, _lib.dptr(emb),
                                                        C.byref(t), _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
@@ -494,14 +502,15 @@ class _HipTrunk(torch.autograd.Function):
         enc._gen_counter = getattr(enc, "_gen_counter", 0) + 1
         enc._frag_owner = enc._gen_counter
         W1 = Fr // 5
-        mask = None
-        if drop_p > 0.0:
-            mask = (torch.rand(B, enc.n_sub, 32, enc.split // enc.sub, W1, device=logmel.device) >= drop_p).to(torch.uint8)
+        # Dropout after the first pooling (src/model.py:118): the mask is drawn inside the pooling epilogue (Philox keyed by a seed
+        # taken from torch's CPU generator: reproducible under torch.manual_seed, no 87 M-element rand / compare / cast launches)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if drop_p > 0.0 else None
         # every forward pass gets its OWN activation workspace (the caching allocator hands the previous step's block back, so a
         # plain training loop allocates nothing): several forward passes may be alive at once -- retained graphs, two
         # forwards before one backward -- each backward finds its activations in the workspace its context holds
         enc._ws_train = None
-        _, t = enc.forward_train(logmel, film=film, head=False, drop1_mask=mask, drop1_p=drop_p, sync=sync)
+        _, t = enc.forward_train(logmel, film=film, head=False, drop1_p=drop_p, sync=sync, drop1_seed=seed)
+        mask = t.get("drop1_mask")
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync = enc, drop_p, (B, Fr), sync
         ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode
         # (the workspace rides with the saved tensors: autograd releases it with them after a backward that does not retain the graph)

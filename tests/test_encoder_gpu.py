@@ -1160,3 +1160,54 @@ def test_hip_training_step_matches_the_reference_training_fixture(tag, precision
         print(f"[{tag} {precision} {lossname}] near-tie bands {sorted(tie_bands)}; worst five: " +
               ", ".join(f"{n.split('audio_encoder.')[-1]} {a:.1e} (ref fp32 {b:.1e}{', ' + w if w else ''})" for a, b, n, w in rows[:5]))
         assert not bad, bad
+
+
+def test_dropout_drawn_inside_the_pooling_epilogue():
+    """Dropout after the first pooling (src/model.py:118, p = 0.3) drawn by the kernel: element o is kept iff
+    philox2x32-10(seed, o) >= p * 2^32.  Checked: pool1 == where(mask, undropped / (1 - p), 0) bit for bit with the mask the kernel
+    returns; the same seed gives the same mask and another seed a different one; the keep rate is 1 - p (87 k elements per clip:
+    within 4 sigma); the draws of a clip's elements do not depend on the batch around it (a pure function of seed and element
+    index); and the training step with dropout on is bit-deterministic under torch.manual_seed."""
+    from mst_amd.model import HipEncoder
+    cfg = cases.CFG_DEFAULT
+    model, _ = build_model(cfg)
+    B, T = 3, 44100
+    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0).cuda()
+    stems = omel.tensor_to_stems_dict(x)
+    feats = (torch.randn(B, 64, generator=torch.Generator().manual_seed(3)) * 2.0).cuda()
+    enc = HipEncoder(model, "fp32")
+    enc.update_trunk_params(*_stacked_trunk_params(model))
+    with torch.no_grad():
+        lm = model.audio_encoder.mel_preprocessor(stems)
+        film = model.film_encoder.film_head(model.film_encoder.feature_mlp(feats))
+        _, t0 = enc.forward_train(lm, film=film, head=False)
+        _, t1 = enc.forward_train(lm, film=film, head=False, drop1_p=0.3, drop1_seed=1234567)
+        _, t2 = enc.forward_train(lm, film=film, head=False, drop1_p=0.3, drop1_seed=1234567)
+        _, t3 = enc.forward_train(lm, film=film, head=False, drop1_p=0.3, drop1_seed=1234568)
+        _, t4 = enc.forward_train(lm[:1].contiguous(), film=film[:1].contiguous(), head=False, drop1_p=0.3, drop1_seed=1234567)
+    m1 = t1["drop1_mask"]
+    assert m1.dtype == torch.uint8 and m1.shape == t0["pool1"].shape
+    # NB the batch statistics of a 1-clip batch differ, the MASK of clip 0 must not
+    assert torch.equal(t4["drop1_mask"][0], m1[0])
+    assert torch.equal(t1["pool1"], torch.where(m1.bool(), t0["pool1"] * (1.0 / 0.7), torch.zeros_like(t0["pool1"])))
+    assert torch.equal(m1, t2["drop1_mask"]) and torch.equal(t1["pool_in"], t2["pool_in"])
+    assert not torch.equal(m1, t3["drop1_mask"])
+    n = m1.numel()
+    keep = m1.float().mean().item()
+    assert abs(keep - 0.7) <= 4.0 * (0.7 * 0.3 / n) ** 0.5 + 1e-4, keep
+    # neighbouring elements / channels / clips are uncorrelated at the level a dropout mask needs
+    a = m1.float() - 0.7
+    for sh, dim in ((1, 4), (1, 3), (1, 2), (1, 0)):
+        c = (a * torch.roll(a, sh, dim)).mean().item() / 0.21
+        assert abs(c) < 6.0 / n ** 0.5 + 2e-3, (dim, c)
+    # end to end: the module's training step with dropout ON is reproducible under the torch seed
+    model.train()
+    model.train_backend = "hip-strict"
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(99)
+        model.zero_grad()
+        emb = model(stems, feats)
+        emb.square().sum().backward()
+        outs.append((emb.detach().clone(), model.audio_encoder.subnet_cnns[5].conv1.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
