@@ -2354,7 +2354,7 @@ struct WgradParams {
 
 // NW waves per workgroup (4: two independent workgroups per CU, so that one's loads / barrier overlap the other's MFMAs)
 // SUB: pool height of the layer (tile = SUB rows x 40 / 80 columns, patch 8 x (SUB + 6) x 46 / 86)
-template <int SUB, int NW, int DBG>   // DBG: timing experiments (MST_WGRAD_DBG): 1 no dy/patch refetch, 2 no staging/barrier, 3 both
+template <int SUB, int NW>
 __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams p) {
   using C = CC<1, SUB>;
   constexpr int PR = C::PR, PC = C::PC, CHS = PR * PC, PATCH = 8 * CHS;
@@ -2432,8 +2432,6 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     dy_src = reinterpret_cast<const f32x4*>(p.dy + u * 64 * 20);
   };
   auto prefetch_piece = [&](int i, float (&pf)[RPW], f32x4 (&dq)[NDY], unsigned& pmask) __attribute__((always_inline)) {
-    if ((DBG & 8) && i < RPW) return;
-    if ((DBG & 16) && i >= RPW) return;
     if (i < RPW) {
       const int idx = wave * RPW + i, row = min(idx / NCV, 8 * PR - 1), cv = idx % NCV;
       const int cc = row / PR, r = row % PR, col = lane + 64 * cv;
@@ -2523,33 +2521,32 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int t5 = 0; t5 < 5; ++t5) ac[c][t5] = reinterpret_cast<const f32x4*>(dybuf[buf])[(c * 64 + lane) * 5 + t5];
-    // B operands of an N-tile are read from LDS as a block of 20 while the 40 MFMAs of the previous N-tile run
-    float bq[2][20];
-    auto load_b = [&](int k, float (&b)[20]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int e = 0; e < 20; ++e) {
-        const int wv = e / C::WIN, pos = e % C::WIN;
-        b[e] = pb[nbase[k] + (pos / 5) * PC + 5 * wv + pos % 5];
-      }
+    // B operands: one float per k-step, read from LDS into a ring of 8 FIVE k-steps (320 matrix cycles) ahead, one read behind
+    // the first MFMA of every step (pinned by sched_barrier).  Before, a block of 20 reads stood in front of every N-tile, and the
+    // two waves of a SIMD -- in lockstep, one barrier per tile -- issued theirs together while the matrix pipe idled.
+    constexpr int NS = KF * 20, LA = 5;
+    float bq[8];
+    auto read_b = [&](int s2) __attribute__((always_inline)) {
+      const int k2 = s2 / 20, e2 = s2 % 20, wv = e2 / C::WIN, pos = e2 % C::WIN;
+      bq[s2 & 7] = pb[nbase[k2] + (pos / 5) * PC + 5 * wv + pos % 5];
     };
-    load_b(0, bq[0]);
+#pragma unroll
+    for (int s2 = 0; s2 < LA; ++s2) read_b(s2);
     int piece = 0;
 #pragma unroll
-    for (int k = 0; k < KF; ++k) {   // the wave's own full N-tiles
-      if (k + 1 < KF) load_b(k + 1, bq[(k + 1) & 1]);
+    for (int s1 = 0; s1 < NS; ++s1) {   // the wave's own full N-tiles, flat step s1 = 20 k + e
+      const int k = s1 / 20, e = s1 % 20;
+      const float b = bq[s1 & 7];
+      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
+      if (s1 + LA < NS) read_b(s1 + LA);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int e = 0; e < 20; ++e) {
-        const float b = bq[k & 1][e];
-        acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
-        acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
-        // one prefetch instruction per 10 MFMAs (12 slots), or per 5 when the tile needs more than 12 pieces
-        if (!(DBG & 1) && (RPW + NDY > 12 ? ((e % 5) == 1 || (e % 5) == 3) : (e % 5) == 2)) {
-          prefetch_piece(piece, pfn, dqn, pmn);
-          ++piece;
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
+      // one prefetch instruction per 10 MFMAs (12 slots), or per 5 when the tile needs more than 12 pieces
+      if ((RPW + NDY > 12 ? ((e % 5) == 1 || (e % 5) == 3) : (e % 5) == 2)) {
+        prefetch_piece(piece, pfn, dqn, pmn);
+        ++piece;
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (SHARED) {   // the last, shared N-tile: this wave's share of its 20 k-steps
 #pragma unroll
@@ -2564,11 +2561,9 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
         }
       }
     }
-    if (!(DBG & 2)) {
-      stage(buf ^ 1, pfs, pms);
-      stage_dy(buf ^ 1, dqs);
-      if (!(DBG & 4)) __syncthreads();
-    }
+    stage(buf ^ 1, pfs, pms);
+    stage_dy(buf ^ 1, dqs);
+    __syncthreads();
   };
   for (int s = s_begin; s < s_end; s += 2) {
     body(s, 0, pfA, dqA, pmA, pfB, dqB, pmB);
@@ -2590,7 +2585,11 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   constexpr int NPF = 4;        // patch elements per thread: flat index f = tid + 512 i over [8*14 rows][16 pitch]
   constexpr int NDY = 2;        // float4 of dy per thread: 4 * 64 * 16 floats per tile
   __shared__ float patch[2][PATCH];
-  __shared__ __attribute__((aligned(16))) float dybuf[2][4 * 64 * 16];
+  constexpr int DYP = 20;       // floats per (M-tile, lane) row of the LDS copy of dy: 16 values + 4 of padding -- 5 units of 16
+                                // bytes per lane, and lane * 5 mod 16 is a permutation inside every 16-lane group of a ds_read_b128:
+                                // the A-operand reads are conflict-free (at the natural pitch of 4 units they were 4-way conflicts,
+                                // SQ_LDS_BANK_CONFLICT 73 % of the LDS cycles, the LDS 57 % busy beside a 73 % busy matrix pipe)
+  __shared__ __attribute__((aligned(16))) float dybuf[2][4 * 64 * DYP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -2667,7 +2666,10 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
       if (row < 8 * PR && col < PC) patch[buf][row * PC + col] = ((pmask >> i) & 1u) ? pf[i] : 0.f;
     }
 #pragma unroll
-    for (int i = 0; i < NDY; ++i) reinterpret_cast<f32x4*>(dybuf[buf])[tid + i * kConvThreads] = dq[i];
+    for (int i = 0; i < NDY; ++i) {
+      const int idx = tid + i * kConvThreads;   // float4 number: (M-tile, lane) row idx >> 2, quarter idx & 3
+      reinterpret_cast<f32x4*>(dybuf[buf])[(idx >> 2) * (DYP / 4) + (idx & 3)] = dq[i];
+    }
   };
 
   f32x4 acc[4][KN];
@@ -2723,34 +2725,40 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
     __builtin_amdgcn_sched_barrier(0);
     const float* pb = patch[buf];
     const float* dyl = dybuf[buf];
-    // A operands (dy, 4 M-tiles x 16 k-steps): read from the LDS copy four k-steps at a time inside each N-tile -- all 64
-    // values resident next to 64 accumulators, the B blocks and two prefetch sets overflowed the register file (93 spills)
-    f32x4 ac[4];
-    const bool low = 8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.in_rows;   // at most rows 8tr, 8tr+1 exist   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
-    float bq[2][16];
-    auto load_b = [&](int k, float (&b)[16]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) b[e] = pb[nbase[k] + (e >> 2) * PC + (e & 3)];
-    };
-    load_b(0, bq[0]);
+    // Explicit software pipeline (as in the forward kernels): between the MFMAs of a k-step the wave issues the LDS reads of LATER
+    // steps -- the B operand (one float, ring of 4: three k-steps = 384 matrix cycles ahead) and, once per group of four
+    // k-steps, the next group's A operands (4 x 16 bytes per M-tile, one group = 512 cycles ahead) -- and two global prefetch
+    // instructions per N-tile.  Before, the A reads sat directly in front of their MFMAs and a block of 16 B reads in front of
+    // every N-tile: both waves of a SIMD (they run in lockstep, one barrier per tile) stalled on them together.
+    const bool low = 8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.in_rows;   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
     auto mma = [&](auto ne_c) __attribute__((always_inline)) {   // NE k-steps per N-tile: 16, or 8 in the low tiles
-      constexpr int NE = decltype(ne_c)::value;
+      constexpr int NE = decltype(ne_c)::value, NS = KF * NE;   // flat step s = k * NE + e
+      constexpr int LA = 3;                                     // B look-ahead in k-steps
+      f32x4 ag[2][4];
+      float bq[4];
+      auto read_b = [&](int s2) __attribute__((always_inline)) {
+        const int k2 = s2 / NE, e2 = s2 % NE;
+        bq[s2 & 3] = pb[nbase[k2] + (e2 >> 2) * PC + (e2 & 3)];
+      };
+      auto read_a = [&](int grp) __attribute__((always_inline)) {   // group = 4 k-steps of one N-tile: the same dy values for every N-tile
+        const int q = grp % (NE / 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ag[grp & 1][c] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * (DYP / 4) + q];
+      };
+      read_a(0);
+#pragma unroll
+      for (int s2 = 0; s2 < LA; ++s2) read_b(s2);
       int piece = 0;
 #pragma unroll
-      for (int k = 0; k < KF; ++k) {
-        if (k + 1 < KF) load_b(k + 1, bq[(k + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int s1 = 0; s1 < NS; ++s1) {
+        const int k = s1 / NE, e = s1 % NE, grp = s1 / 4;
+        const float b = bq[s1 & 3];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-          if ((e & 3) == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ac[c] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 4 + (e >> 2)];
-          }
-          const float b = bq[k & 1][e];
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[c][e & 3], b, acc[c][k], 0, 0, 0);
-          if ((e & 3) == 2 && e < 8) {   // two prefetch instructions per N-tile, in the k-steps every tile executes
+        for (int c = 0; c < 4; ++c) {
+          acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[grp & 1][c][e & 3], b, acc[c][k], 0, 0, 0);
+          if (c == 0 && s1 + LA < NS) read_b(s1 + LA);
+          if (c == 1 && (e & 3) == 0 && s1 + 4 < NS) read_a(grp + 1);
+          if (c == 2 && (e & 3) == 2 && e < 8) {   // two prefetch instructions per N-tile, in the k-steps every tile executes
             prefetch_piece(piece, pfn, dqn, pmn);
             ++piece;
           }
@@ -2769,7 +2777,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
           const float b = pb[sh_base + (e >> 2) * PC + (e & 3)] * sh_mask;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float a = dyl[(c * 64 + lane) * 16 + e];
+            const float a = dyl[(c * 64 + lane) * DYP + e];
             acc[c][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c][KF], 0, 0, 0);
           }
         }
@@ -3828,8 +3836,8 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
     const dim3 gw((int)std::min<long long>(e->num_cus, items));
     if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<1, 3>), gw, dim3(kConvThreads), lds3, st, fp);
     else hipLaunchKernelGGL((wgrad_f16_kernel<1, 1>), gw, dim3(kConvThreads), lds1, st, fp);
-  } else if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
-  else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8, 0>), dim3(g8), dim3(512), 0, st, wp);
+  } else if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8>), dim3(g8), dim3(512), 0, st, wp);
+  else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8>), dim3(g8), dim3(512), 0, st, wp);
   hipLaunchKernelGGL(det_to_float_kernel, dim3((unsigned)((ndw + 255) / 256)), dim3(256), 0, st, dwa, dw, ndw, unscale);
   MST_HIP_CHECK(hipGetLastError());
   return MST_OK;

@@ -493,9 +493,15 @@ class _HipTrunk(torch.autograd.Function):
     last_timing = None
 
     @staticmethod
-    def forward(ctx, enc, logmel, film, c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b, drop_p, sync=None):
+    def forward(ctx, enc, logmel, film, flat, drop_p, sync, *params):
+        """flat: the 8 parameter families (conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.*, bn2.*) stacked over the
+        sub-bands -- the storage the per-band Parameters are views of (MixingStyleEncoder._trunk_flat), so no stack kernels run;
+        params: those Parameters themselves, family-major, only so that autograd routes the gradients to them (the backward
+        returns views of the stacked gradients, which AccumulateGrad adopts without a copy when .grad is None)."""
         B, _, M, Fr = logmel.shape
-        trunk = (c1w, c1b, bn1w, bn1b, c2w, c2b, bn2w, bn2b)
+        trunk = tuple(b.clone() for b in flat)   # this pass's parameter snapshot (8 small copies; an optimizer step or another
+        #                                          pass may rewrite the live storage before this pass's backward runs)
+        ctx.n_sub = flat[0].shape[0]
         enc.update_trunk_params(*trunk)
         # which forward pass's parameters the encoder's weight fragments hold: a MONOTONIC pass counter names the passes, the
         # owner is rewritten on every fragment rebuild (forward or backward) and never fed back into the counter
@@ -558,8 +564,9 @@ class _HipTrunk(torch.autograd.Function):
         if _TRAIN_TIMING:
             torch.cuda.synchronize()
             _HipTrunk.last_timing = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
-        return (None, None, dfilm, gw1, gb1, dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(),
-                gw2, gb2, dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous(), None, None)
+        fams = (gw1, gb1, dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(), gw2, gb2, dbn2[..., 0].contiguous(),
+                dbn2[..., 1].contiguous())
+        return (None, None, dfilm, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
 
 
 class MixingStyleEncoder(nn.Module):
@@ -606,6 +613,35 @@ class MixingStyleEncoder(nn.Module):
         return torch.is_grad_enabled() and (self.training or mixing_features.requires_grad) and \
             any(p.requires_grad for p in self.parameters())
 
+    _TRUNK_FAMILIES = (("conv1", "weight"), ("conv1", "bias"), ("bn1", "weight"), ("bn1", "bias"),
+                       ("conv2", "weight"), ("conv2", "bias"), ("bn2", "weight"), ("bn2", "bias"))
+
+    def _trunk_flat(self):
+        """The conv / BatchNorm parameters of the sub-band CNNs as views of 8 STACKED tensors (one storage per family, stacked
+        over the sub-bands): the training kernels read all sub-bands of a family as one tensor, and with the Parameters living
+        inside it no torch.stack (11 copies per family, forward) and no per-band gradient copies (backward) run per step.
+        Parameter objects, names, shapes and state_dict are unchanged; `.to()` / re-materialisation is detected by pointer and the
+        storage is re-stacked.  Returns (stacked tensors, Parameters family-major)."""
+        cn = self.audio_encoder.subnet_cnns
+        params = [getattr(getattr(c, m), a) for m, a in self._TRUNK_FAMILIES for c in cn]
+        flat = getattr(self, "_trunk_flat_bufs", None)
+        ns = len(cn)
+        ok = flat is not None and len(flat) == 8 and all(
+            b.shape[0] == ns and params[f * ns].data_ptr() == b.data_ptr() and
+            params[f * ns + ns - 1].data_ptr() == b[ns - 1].data_ptr() and params[f * ns].dtype == b.dtype
+            for f, b in enumerate(flat))
+        if not ok:
+            flat = []
+            with torch.no_grad():
+                for f in range(8):
+                    ps = params[f * ns:(f + 1) * ns]
+                    buf = torch.stack([q.detach() for q in ps])
+                    for i, q in enumerate(ps):
+                        q.data = buf[i]
+                    flat.append(buf)
+            self._trunk_flat_bufs = flat
+        return flat, params
+
     def _forward_train_hip(self, logmel, mixing_features):
         """Training forward with the trunk in libmst.so (see _HipTrunk); FiLM MLP and attention head stay torch modules."""
         ae, fe = self.audio_encoder, self.film_encoder
@@ -629,7 +665,7 @@ class MixingStyleEncoder(nn.Module):
             want = "fp32"
         enc.set_train_precision(want)
         cn = ae.subnet_cnns
-        st = lambda f: torch.stack([f(c) for c in cn])  # noqa: E731
+        trunk_flat, trunk_params = self._trunk_flat()
         flat = fe.film_head(fe.feature_mlp(mixing_features))
         p = cn[0].dropout1.p if self.training else 0.0
         sync = None
@@ -639,10 +675,7 @@ class MixingStyleEncoder(nn.Module):
                 sync = DistSync()
         elif self.sync_bn:
             sync = self.sync_bn
-        pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, st(lambda c: c.conv1.weight), st(lambda c: c.conv1.bias),
-                                            st(lambda c: c.bn1.weight), st(lambda c: c.bn1.bias),
-                                            st(lambda c: c.conv2.weight), st(lambda c: c.conv2.bias),
-                                            st(lambda c: c.bn2.weight), st(lambda c: c.bn2.bias), float(p), sync)
+        pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, trunk_flat, float(p), sync, *trunk_params)
         with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
             B, Fr = logmel.shape[0], logmel.shape[-1]
             if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different
