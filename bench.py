@@ -297,6 +297,10 @@ def main():
         crit_t = InfoNCELoss(0.1, gather=world > 1)
         amp = a.train_precision == "amp"
         scaler = torch.amp.GradScaler("cuda") if amp else None
+        reducer = None
+        if world > 1:
+            from mst_amd.dist import GradientReducer
+            reducer = GradientReducer(model)
 
         def train_step():
             with torch.no_grad():
@@ -306,14 +310,8 @@ def main():
                 loss = crit_t(emb, labels)
             opt.zero_grad(set_to_none=True)
             (scaler.scale(loss) if amp else loss).backward()
-            if world > 1:   # data-parallel: sum the parameter gradients (see loss.InfoNCELoss) in ONE 13 MB all-reduce
-                gs = [prm.grad for prm in model.parameters() if prm.grad is not None]
-                flat = torch.cat([g_.reshape(-1) for g_ in gs])
-                dist.all_reduce(flat)
-                off = 0
-                for g_ in gs:
-                    g_.copy_(flat[off:off + g_.numel()].view_as(g_))
-                    off += g_.numel()
+            if reducer is not None:   # data-parallel: the parameter gradients are summed over the ranks (see loss.InfoNCELoss) by
+                reducer.wait()        # four bucketed all-reduces that were launched DURING the backward pass (mst_amd/dist.py)
             if amp:
                 scaler.step(opt)
                 scaler.update()

@@ -493,7 +493,7 @@ class _HipTrunk(torch.autograd.Function):
     last_timing = None
 
     @staticmethod
-    def forward(ctx, enc, logmel, film, flat, drop_p, sync, *params):
+    def forward(ctx, enc, logmel, film, flat, drop_p, sync, reducer, *params):
         """flat: the 8 parameter families (conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.*, bn2.*) stacked over the
         sub-bands -- the storage the per-band Parameters are views of (MixingStyleEncoder._trunk_flat), so no stack kernels run;
         params: those Parameters themselves, family-major, only so that autograd routes the gradients to them (the backward
@@ -517,7 +517,7 @@ class _HipTrunk(torch.autograd.Function):
         enc._ws_train = None
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_p=drop_p, sync=sync, drop1_seed=seed)
         mask = t.get("drop1_mask")
-        ctx.enc, ctx.drop_p, ctx.dims, ctx.sync = enc, drop_p, (B, Fr), sync
+        ctx.enc, ctx.drop_p, ctx.dims, ctx.sync, ctx.reducer = enc, drop_p, (B, Fr), sync, reducer
         ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode
         # (the workspace rides with the saved tensors: autograd releases it with them after a backward that does not retain the graph)
         ctx.save_for_backward(logmel, t["pool1"], mask, enc._ws_train, *trunk)
@@ -554,6 +554,10 @@ class _HipTrunk(torch.autograd.Function):
         gw2 = enc.conv2_wgrad(p1, B, Fr)          # weight gradient on dy2 in accumulator order
         gb2 = torch.zeros(ns, 64, device=logmel.device)   # exactly 0 in front of a batch-statistics BatchNorm
         mark("conv2_wgrad")
+        dbn2w, dbn2b = dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous()
+        reducer = ctx.reducer
+        if reducer is not None:   # data parallel: the conv2-side gradients are final -- their all-reduce runs behind the rest of
+            reducer.reduce_stacked("conv2", [gw2, gb2, dbn2w, dbn2b])   # this backward (dist.GradientReducer)
         dp1 = enc.conv2_dgrad(dy2, B, Fr, mask, ctx.drop_p)   # input gradient (Dropout mask fused)
         mark("conv2_dgrad")
         _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
@@ -564,9 +568,11 @@ class _HipTrunk(torch.autograd.Function):
         if _TRAIN_TIMING:
             torch.cuda.synchronize()
             _HipTrunk.last_timing = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
-        fams = (gw1, gb1, dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous(), gw2, gb2, dbn2[..., 0].contiguous(),
-                dbn2[..., 1].contiguous())
-        return (None, None, dfilm, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
+        dbn1w, dbn1b = dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous()
+        if reducer is not None:
+            reducer.reduce_stacked("conv1", [gw1, gb1, dbn1w, dbn1b])
+        fams = (gw1, gb1, dbn1w, dbn1b, gw2, gb2, dbn2w, dbn2b)
+        return (None, None, dfilm, None, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
 
 
 class MixingStyleEncoder(nn.Module):
@@ -675,7 +681,8 @@ class MixingStyleEncoder(nn.Module):
                 sync = DistSync()
         elif self.sync_bn:
             sync = self.sync_bn
-        pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, trunk_flat, float(p), sync, *trunk_params)
+        pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, trunk_flat, float(p), sync, getattr(self, "_grad_reducer", None),
+                                            *trunk_params)
         with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
             B, Fr = logmel.shape[0], logmel.shape[-1]
             if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different

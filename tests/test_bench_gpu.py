@@ -55,3 +55,14 @@ def test_train_step_line_by_precision(precision):
     out = _bench(["--train", "--train-precision", precision, "--steps", "2", "--warmup", "1", "--triplets", "3", "--seconds", "2"])
     assert out["config"]["train_precision"] == precision and out["config"]["train_backend"] == "hip"
     assert out["value"] > 0 and out["config"]["loss"] == out["config"]["loss"] and "NOT THE CONTRACT LINE" in out["config"]["workload"]
+
+
+def test_gpus_2_training_step_with_overlapped_gradient_reduction():
+    """`bench.py --train --gpus 2`: two ranks (both on the box's GPU, gloo), the hand-written trunk launching its conv2-side and
+    conv1-side gradient buckets itself during the backward (mst_amd/dist.GradientReducer), the pooling head / FiLM MLP buckets from
+    autograd hooks; with cross-rank BatchNorm statistics on top (`--sync-bn`)."""
+    for extra in ([], ["--sync-bn"]):
+        out = _bench(["--gpus", "2", "--train", "--steps", "2", "--warmup", "1", "--triplets", "2", "--seconds", "2"] + extra,
+                     MST_BENCH_ONE_GPU="1", MST_BENCH_BACKEND="gloo")
+        assert out["n_gpus"] == 2 and out["world"] == 2 and out["value"] > 0
+        assert out["config"]["sync_bn"] == bool(extra) and out["config"]["loss"] == out["config"]["loss"]

@@ -45,13 +45,15 @@ def _worker(rank, world, port, precision, ret, backend="gloo"):
         with torch.no_grad():
             lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
         sl = slice(cut[rank], cut[rank + 1])
+        from mst_amd.dist import GradientReducer
+        red = GradientReducer(model)     # C2: bucketed all-reduces launched DURING the backward (the trunk launches its own two)
         loss = (model.forward_from_logmel(lm[sl].contiguous(), feats[sl]) * R[sl]).sum()
         loss.backward()
+        order = red.wait()
+        assert order[0] == "head" and order[-1] == "film" and order.index("conv2") < order.index("conv1"), order
         tot = loss.detach().clone()
         dist.all_reduce(tot)
         grads = {n: p.grad.clone() for n, p in model.named_parameters()}
-        for n in grads:
-            dist.all_reduce(grads[n])                      # the trainer's gradient all-reduce (C2)
         if rank == 0:
             lw = (whole.forward_from_logmel(lm, feats) * R).sum()
             lw.backward()
