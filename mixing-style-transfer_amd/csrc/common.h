@@ -63,18 +63,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // depend on the order in which workgroups happen to arrive; integer atomics do not.  A value x is split exactly into
 // its integer part and its fraction scaled by 2^48, and both go into 64-bit integer accumulators: the total is the
 // same bit pattern whatever the arrival order (the reference asks for deterministic training, src/train.py:30).
-// Range |x| < 2^62; resolution 2^-48 absolute (3.6e-15) -- far below fp32 / the double partial sums it replaces;
+// Range of a total |x| < 2^50; resolution 2^-48 absolute (3.6e-15) -- far below fp32 / the double partial sums it replaces;
 // up to 2^14 contributions per accumulator without overflow of the fraction word.
+// NON-FINITE contributions (a NaN / Inf that entered the trunk, an overflowed AMP loss scale) POISON the accumulator: its integer
+// word is raised to kDetPoison and det_get returns NaN, so the statistics, the gradients and everything behind them come out
+// non-finite and the caller's NaN checks / GradScaler see the step for what it is (an integer cast of NaN would be garbage that
+// looks finite).  The marker survives the integer SUM all-reduce of cross-rank statistics for up to 64 poisoned ranks.
 struct DetAcc {
   long long hi, lo;
 };
+constexpr long long kDetPoison = (1LL << 62) + (1LL << 55), kDetLimit = 1LL << 50;
 __device__ __forceinline__ void det_add(DetAcc* a, double x) {
+  if (!(fabs(x) < 1.0e15)) {   // NaN, Inf, or beyond the accumulator's range
+    atomicMax(&a->hi, kDetPoison);
+    return;
+  }
   const double hi = rint(x);
   const double lo = rint((x - hi) * 281474976710656.0);   // 2^48; |x - hi| <= 0.5
   atomicAdd(reinterpret_cast<unsigned long long*>(&a->hi), (unsigned long long)(long long)hi);
   atomicAdd(reinterpret_cast<unsigned long long*>(&a->lo), (unsigned long long)(long long)lo);
 }
 __device__ __forceinline__ double det_get(const DetAcc& a) {
+  if (a.hi >= kDetLimit || a.hi <= -kDetLimit) return __builtin_nan("");
   return (double)a.hi + (double)a.lo * (1.0 / 281474976710656.0);
 }
 

@@ -864,7 +864,12 @@ __global__ __launch_bounds__(64) void f16_scale_kernel(const float2* __restrict_
 }
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ _Float16 to_f16_sat(float v) { return (_Float16)fminf(fmaxf(v, -65504.f), 65504.f); }
+// saturating conversion of FINITE values (the power-of-two range scales keep real data far below the ceiling; this only guards the
+// bound's slack); a NaN or an infinity stays one -- fminf / fmaxf would turn a NaN into -65504 and hide a diverged step from the
+// caller's GradScaler / NaN checks (src/train.py:251-262 skips such steps)
+__device__ __forceinline__ _Float16 to_f16_sat(float v) {
+  return (_Float16)(__builtin_isfinite(v) ? fminf(fmaxf(v, -65504.f), 65504.f) : v);
+}
 // weight pre-scale of the f16 fragments: an exact power of two per (band, output channel), chosen on the host so that the
 // filter's largest |w| lands in [2^13, 2^14) -- wl = w - wh stays a normal f16 whatever the weights' magnitude -- and
 // folded back per channel in the epilogue (ConvParams::f16_winv)
@@ -1966,7 +1971,8 @@ __global__ void bn_fold_kernel(const FoldParams p) {   // grid (nsub, B), block 
   const size_t i = (size_t)band * p.cout + ch;
   const double count = p.clips ? (double)p.clips[0] * p.per_clip : p.count;
   const double mean = mst::det_get(p.stats[i * 2]) / count;
-  const double var = fmax(mst::det_get(p.stats[i * 2 + 1]) / count - mean * mean, 0.0);
+  const double var0 = mst::det_get(p.stats[i * 2 + 1]) / count - mean * mean;
+  const double var = var0 != var0 ? var0 : fmax(var0, 0.0);   // (fmax would turn a poisoned, NaN statistic into 0)
   const double invstd = 1.0 / sqrt(var + (double)p.eps);
   if (b == 0) p.bnstat[i] = make_float2((float)mean, (float)invstd);
   const float* fl = p.film + ((size_t)b * p.nsub + band) * 192;
@@ -2072,6 +2078,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
         const bool mine = nh == 1 || pos / 5 == hr;
         m = mine ? fmaxf(m, fmaf(v[wv * C::WIN + pos], ac.x, ac.y)) : m;
       }
+      m = (ac.x + ac.y == ac.x + ac.y) ? m : ac.x + ac.y;   // poisoned batch statistics (NaN affine): fmaxf would drop the NaN and hand on zeros
       const int pc = 4 * C::WPG * tc + C::WPG * g + wv;
       const int prow = nh == 1 ? tr : 2 * tr + hr;
       if (pc < p.out_cols && prow < p.out_rows) {
@@ -2098,6 +2105,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
     float m = 0.f;
 #pragma unroll
     for (int e = 0; e < NV; ++e) m = fmaxf(m, fmaf(v[e], ac.x, ac.y));
+    m = (ac.x + ac.y == ac.x + ac.y) ? m : ac.x + ac.y;   // poisoned batch statistics: see layer 1
     const int pr = 2 * tr + (g >> 1), pc = 2 * tc + (g & 1);
     if (pr < p.out_rows && pc < p.out_cols)
       p.out[(((size_t)clip * p.nsub + band) * C::COUT + ch) * p.out_rows * p.out_cols + (size_t)pr * p.out_cols + pc] = m;

@@ -1211,3 +1211,24 @@ def test_dropout_drawn_inside_the_pooling_epilogue():
         emb.square().sum().backward()
         outs.append((emb.detach().clone(), model.audio_encoder.subnet_cnns[5].conv1.weight.grad.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("precision", ["f16", "f16x3"])
+def test_non_finite_values_stay_visible_in_f16_training(precision):
+    """A NaN that enters the trunk (here: one NaN sample in a stem) must come out as non-finite embeddings and gradients, as it
+    does under the reference's autocast step -- whose GradScaler then skips the optimizer step (src/train.py:251-262).  The
+    float16 stores of the training kernels saturate FINITE values only; a clamp that maps NaN to -65504 would hand the trainer
+    finite garbage instead."""
+    model, _ = build_model(cases.CFG_DEFAULT)
+    model.train()
+    model.train_backend, model.train_precision = "hip-strict", precision
+    B, T = 2, 44100
+    x = torch.stack([cases.synth_clip(c, T) for c in range(B)], 0)
+    x[1, 2, 20000] = float("nan")
+    feats = (torch.randn(B, 64, generator=torch.Generator().manual_seed(3)) * 2.0).cuda()
+    emb = model(omel.tensor_to_stems_dict(x.cuda()), feats)
+    emb.sum().backward()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(emb).all()
+    g = torch.stack([c.conv1.weight.grad for c in model.audio_encoder.subnet_cnns])
+    assert not torch.isfinite(g).all()
