@@ -770,7 +770,9 @@ class MixingStyleEncoder(nn.Module):
         mf = mixing_features.to(logmel.device)
         if feats is not None:
             mf = torch.where(is_deferred(mf), feats.to(mf.dtype), mf)
-        else:   # no extractor layout of this size: the rows must be real values -- checked on the device, without a host sync
-            torch._assert_async(~is_deferred(mf).any(), f"mixing_features holds deferred placeholder rows but feature_dim="
-                                f"{self.film_encoder.feature_dim} is not a MixingFeatureExtractor layout")
+        elif bool(is_deferred(mf).any()):
+            # no extractor layout of this size (an unusual feature_dim), so nothing can fill a placeholder: refuse, as a Python
+            # error the caller can catch.  This branch alone reads one flag back; the extractor layouts above never sync.
+            raise ValueError(f"mixing_features holds deferred placeholder rows but feature_dim={self.film_encoder.feature_dim} "
+                             "is not a MixingFeatureExtractor layout")
         return self.forward_from_logmel(logmel, mf)
