@@ -235,6 +235,15 @@ int mst_encoder_train_stats_buffer(const mst_encoder* enc, int layer, int B, int
 int mst_encoder_forward_train(const mst_encoder* enc, const float* logmel, int frames, const float* feats, int B,
                               float* emb, const mst_encoder_train_taps* taps, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* The same with a described log-mel (mst_logmel_in, above).  The float16 training modes (mst_encoder_set_train_precision 1, 2)
+ * read stage A's MST_LOGMEL_CM16 planes directly -- no fp32 -> float16 conversion while staging, no pass for the per-clip
+ * maximum (absmax is required with that layout); the fp32 mode takes MST_LOGMEL_REF only.
+ * mst_encoder_train_layout_supported answers for the CURRENT training precision.  The weight gradient of conv1
+ * (mst_encoder_train_conv1_wgrad_in) must be given the same log-mel.                                                  */
+int mst_encoder_train_layout_supported(const mst_encoder* enc, int layout);
+int mst_encoder_forward_train_in(const mst_encoder* enc, const mst_logmel_in* logmel, int frames, const float* feats, int B,
+                                 float* emb, const mst_encoder_train_taps* taps, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 
 /* Operand precision of the TRAINING kernels (all six entry points below and mst_encoder_forward_train).
  * 0 (default): exact fp32 MFMA.  1: float16 operands, fp32 accumulation -- the arithmetic of the reference's `--use_amp`
@@ -294,6 +303,8 @@ int mst_encoder_train_scale_buffer(const mst_encoder* enc, int B, int frames, si
  * BatchNorm is identically zero and is not computed.                                                            */
 int mst_encoder_train_conv1_wgrad(const mst_encoder* enc, const float* logmel, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream);
+int mst_encoder_train_conv1_wgrad_in(const mst_encoder* enc, const mst_logmel_in* logmel, int B, int frames, float* dw,
+                                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* conv2 weight gradient, same scheme (dy of layer 2 is always left in the workspace in accumulator order by
  * mst_encoder_train_backward_apply(layer 2), next to the NCHW copy it returns).

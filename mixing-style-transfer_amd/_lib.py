@@ -103,6 +103,11 @@ SYMBOLS = {
     "mst_encoder_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_layout_supported": (C.c_int, [C.c_void_p, C.c_int]),
+    "mst_encoder_forward_train_in": (C.c_int, [C.c_void_p, C.POINTER(LogmelIn), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                               C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_conv1_wgrad_in": (C.c_int, [C.c_void_p, C.POINTER(LogmelIn), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p]),
     "mst_encoder_train_backward_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong,
                                                    C.c_longlong, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -3380,9 +3380,33 @@ int mst_encoder_train_scale_buffer(const mst_encoder* e, int B, int frames, size
   return MST_OK;
 }
 
+int mst_encoder_train_layout_supported(const mst_encoder* e, int layout) {
+  if (!e) return 0;
+  if (layout == MST_LOGMEL_REF) return 1;
+  // the float16 training kernels (forward conv1 and its weight gradient) read stage A's float16 planes directly; the fp32
+  // training kernels keep the reference layout
+  if (layout == MST_LOGMEL_CM16) return train_fwd16(e) ? 1 : 0;
+  return 0;
+}
+
 int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int frames, const float* feats, int B, float* emb,
                               const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(e && logmel && (feats || (taps && taps->film_in)), "mst_encoder_forward_train: NULL argument");
+  mst_logmel_in in{};
+  in.layout = MST_LOGMEL_REF, in.data = logmel;
+  return mst_encoder_forward_train_in(e, &in, frames, feats, B, emb, taps, workspace, workspace_bytes, stream);
+}
+
+int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin, int frames, const float* feats, int B, float* emb,
+                                 const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && lin && lin->data && (feats || (taps && taps->film_in)), "mst_encoder_forward_train: NULL argument");
+  const int lay = lin->layout;
+  MST_REQUIRE(mst_encoder_train_layout_supported(e, lay),
+              "mst_encoder_forward_train: log-mel layout %d does not fit the training kernels of precision mode %d (query "
+              "mst_encoder_train_layout_supported)", lay, e->train_f16);
+  MST_REQUIRE(lay != MST_LOGMEL_CM16 || e->train_f16 == 1 || lin->lo, "mst_encoder_forward_train: MST_LOGMEL_CM16 needs the low parts in the split-precision mode");
+  MST_REQUIRE(lay == MST_LOGMEL_REF || ((reinterpret_cast<uintptr_t>(lin->data) | reinterpret_cast<uintptr_t>(lin->lo)) & 15) == 0,
+              "mst_encoder_forward_train: channel-minor log-mel must be 16-byte aligned");
+  const float* logmel = static_cast<const float*>(lin->data);
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_forward_train: need B>0 and frames>=20 (B=%d frames=%d)", B, frames);
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
@@ -3444,8 +3468,14 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
     if (train_fwd16(e)) {   // f16 operands (mode 1) or 3-term split precision (mode 2), fp32 accumulate (encoder_f16train.inc)
       using C = CC<1, 2>;
       unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);   // max |log-mel| per clip: bounds for the range scales
-      MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
-      hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, (long long)8 * e->cfg.n_mels * frames, xmax);
+      if (lin->absmax) {   // stage A found it while it wrote the log-mel
+        MST_HIP_CHECK(hipMemcpyAsync(xmax, lin->absmax, (size_t)B * sizeof(unsigned), hipMemcpyDeviceToDevice, st));
+      } else {
+        MST_REQUIRE(lay == MST_LOGMEL_REF, "mst_encoder_forward_train: MST_LOGMEL_CM16 needs absmax (stage A's per-clip max |log-mel|)");
+        MST_HIP_CHECK(hipMemsetAsync(xmax, 0, (size_t)B * sizeof(unsigned), st));
+        hipLaunchKernelGGL(absmax_kernel, dim3(64, B), dim3(256), 0, st, logmel, (long long)8 * e->cfg.n_mels * frames, xmax);
+      }
+      cp.in_lo = lin->lo, cp.cm_mels = e->cfg.n_mels, cp.cm_overlap = e->cfg.overlap;
       if (e->train_f16 == 1) {   // the raw output is stored as float16 times a per-band power of two
         float* ys1 = reinterpret_cast<float*>(ws + T.t_ys1);
         hipLaunchKernelGGL(f16_yscale_kernel, dim3(ns), dim3(64), 0, st, e->w1norm, e->c1b, 32, xmax, B, static_cast<const float*>(nullptr), ys1);
@@ -3459,12 +3489,21 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
         if (err == hipSuccess)
           err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3, 1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 1, 2, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess)
+          err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_f16x3_kernel<2, 3, 1, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 (f16 train) attribute failed: %s", hipGetErrorString(err));
       }
       cp.f16_winv = e->f16_winv1;
       const h16x8* wf = reinterpret_cast<const h16x8*>(e->w1frag16);
       _Float16* none = nullptr;
-      if (e->train_f16 == 2) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
+      if (lay == MST_LOGMEL_CM16) {   // ready-made float16 operands: 16-byte copies instead of the fp32 -> f16 staging
+        if (e->train_f16 == 2) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 1, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
+        else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 2, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
+      } else if (e->train_f16 == 2) hipLaunchKernelGGL((conv1_f16x3_kernel<2, 3, 1>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
       else hipLaunchKernelGGL((conv1_f16x3_kernel<2, 1, 2>), dim3(g), dim3(kConvThreads), lds, st, cp, wf, none, none);
     } else if (e->sub == 2) {
       using C = CC<1, 2>;
@@ -3807,7 +3846,21 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
 
 int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(e && logmel && dw, "mst_encoder_train_conv1_wgrad: NULL argument");
+  mst_logmel_in in{};
+  in.layout = MST_LOGMEL_REF, in.data = logmel;
+  return mst_encoder_train_conv1_wgrad_in(e, &in, B, frames, dw, workspace, workspace_bytes, stream);
+}
+
+int mst_encoder_train_conv1_wgrad_in(const mst_encoder* e, const mst_logmel_in* lin, int B, int frames, float* dw,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && lin && lin->data && dw, "mst_encoder_train_conv1_wgrad: NULL argument");
+  const int lay = lin->layout;
+  MST_REQUIRE(mst_encoder_train_layout_supported(e, lay),
+              "mst_encoder_train_conv1_wgrad: log-mel layout %d does not fit the training kernels of precision mode %d", lay, e->train_f16);
+  MST_REQUIRE(lay != MST_LOGMEL_CM16 || e->train_f16 == 1 || lin->lo, "mst_encoder_train_conv1_wgrad: MST_LOGMEL_CM16 needs the low parts in the split-precision mode");
+  MST_REQUIRE(lay == MST_LOGMEL_REF || ((reinterpret_cast<uintptr_t>(lin->data) | reinterpret_cast<uintptr_t>(lin->lo)) & 15) == 0,
+              "mst_encoder_train_conv1_wgrad: channel-minor log-mel must be 16-byte aligned");
+  const float* logmel = static_cast<const float*>(lin->data);
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_train_conv1_wgrad: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   if (!workspace || workspace_bytes < T.total)
@@ -3829,7 +3882,7 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
     WgradF16Params fp{logmel, reinterpret_cast<const h16x8*>(ws + T.t_dyg1), dwa, nullptr, B, ns, T.tr1, T.tc1,
                       e->cfg.split_size, frames, e->cfg.n_mels * frames, e->cfg.overlap * frames,
-                      (long long)8 * e->cfg.n_mels * frames};
+                      (long long)8 * e->cfg.n_mels * frames, lin->lo, e->cfg.n_mels, e->cfg.overlap};
     const long long items = (long long)ns * ((B + 7) / 8) * T.tr1 * T.tc1;
     constexpr size_t lds1 = (size_t)(8 * 8 * 46 + 2 * 20 * 64) * 16, lds3 = (size_t)(2 * 8 * 8 * 46 + 2 * 10 * 2 * 64) * 16;
     static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
@@ -3839,10 +3892,19 @@ int mst_encoder_train_conv1_wgrad(const mst_encoder* e, const float* logmel, int
       if (err == hipSuccess)
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1, 1, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<1, 3, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 wgrad (f16) attribute failed: %s", hipGetErrorString(err));
     }
     const dim3 gw((int)std::min<long long>(e->num_cus, items));
-    if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<1, 3>), gw, dim3(kConvThreads), lds3, st, fp);
+    if (lay == MST_LOGMEL_CM16) {
+      if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<1, 3, 2>), gw, dim3(kConvThreads), lds3, st, fp);
+      else hipLaunchKernelGGL((wgrad_f16_kernel<1, 1, 2>), gw, dim3(kConvThreads), lds1, st, fp);
+    } else if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<1, 3>), gw, dim3(kConvThreads), lds3, st, fp);
     else hipLaunchKernelGGL((wgrad_f16_kernel<1, 1>), gw, dim3(kConvThreads), lds1, st, fp);
   } else if (e->sub == 2) hipLaunchKernelGGL((conv1_wgrad_kernel<2, 8>), dim3(g8), dim3(512), 0, st, wp);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<1, 8>), dim3(g8), dim3(512), 0, st, wp);

@@ -255,6 +255,21 @@ class HipEncoder:
         except StopIteration as done:
             return done.value
 
+    @staticmethod
+    def _logmel_in(logmel):
+        """(mst_logmel_in, tensors to keep alive, (B, frames), device) of a reference-layout tensor or a `LogMel`."""
+        if isinstance(logmel, LogMel):
+            return (_lib.LogmelIn(logmel.layout, 0, _lib.dptr(logmel.data), _lib.dptr(logmel.lo), _lib.dptr(logmel.absmax)), logmel,
+                    (logmel.B, logmel.frames), logmel.device)
+        lm = logmel.contiguous().float()
+        return _lib.LogmelIn(_lib.LOGMEL_REF, 0, _lib.dptr(lm), None, None), lm, (lm.shape[0], lm.shape[3]), lm.device
+
+    def train_layout(self):
+        """The log-mel layout the TRAINING kernels of the current precision read fastest: stage A's float16 planes
+        (_lib.LOGMEL_CM16) in the f16 / f16x3 modes, the reference layout in the fp32 mode."""
+        lay = _lib.LOGMEL_CM16
+        return lay if _lib.lib().mst_encoder_train_layout_supported(self._h, lay) else _lib.LOGMEL_REF
+
     def forward_train_steps(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, world=0,
                             drop1_seed=None):
         """Generator form of the train-mode forward.  world = 0: one call of `mst_encoder_forward_train`, nothing is yielded.
@@ -267,16 +282,15 @@ class HipEncoder:
         first pooling); or drop1_seed (int) with drop1_p > 0: the kernel draws the mask itself (Philox, a pure function of
         (seed, element)) and returns it as taps["drop1_mask"].  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
         1/sqrt(biased var + eps)).  The raw conv outputs stay in the workspace for `backward_apply`."""
-        B, _, M, Fr = logmel.shape
+        lin, keep, (B, Fr), dev = self._logmel_in(logmel)
         L = _lib.lib()
         need = L.mst_encoder_train_workspace_bytes(self._h, B, Fr)
         if need == 0:
             raise _lib.MstError("forward_train needs frames >= 20")
-        if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need or self._ws_train.device != logmel.device:
-            self._ws_train = torch.empty(need, dtype=torch.uint8, device=logmel.device)
+        if getattr(self, "_ws_train", None) is None or self._ws_train.numel() < need or self._ws_train.device != dev:
+            self._ws_train = torch.empty(need, dtype=torch.uint8, device=dev)
         if _POISON_WS:   # debugging aid: every byte 0xFF (fp32 NaN) before each forward -- any read of a slot nobody wrote shows up
             self._ws_train.fill_(255)
-        dev = logmel.device
         emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=dev) if head else None
         W1 = Fr // 5
         out = {"film": torch.empty(B, self.n_sub * 192, device=dev),
@@ -292,16 +306,15 @@ class HipEncoder:
         if drop1_seed is not None and drop1_p > 0.0:
             assert mask_c is None, "pass a mask OR a seed"
             mask_out = out["drop1_mask"] = torch.empty(out["pool1"].shape, dtype=torch.uint8, device=dev)
-        lm = logmel.contiguous().float()
         for phase in ((0,) if world == 0 else (1, 2, 3)):
             t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")],
                                       _lib.dptr(film_c), _lib.dptr(mask_c), 1.0 / (1.0 - drop1_p) if mask_c is not None else 1.0,
                                       phase, float(max(world, 1)), _lib.dptr(mask_out), int(drop1_seed or 0) & (2 ** 64 - 1),
                                       float(drop1_p) if mask_out is not None else 0.0)
             with torch.cuda.device(dev):
-                _lib.check(L.mst_encoder_forward_train(self._h, _lib.dptr(lm), Fr, _lib.dptr(feats_c), B, _lib.dptr(emb),
-                                                       C.byref(t), _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
-                           "mst_encoder_forward_train")
+                _lib.check(L.mst_encoder_forward_train_in(self._h, C.byref(lin), Fr, _lib.dptr(feats_c), B, _lib.dptr(emb),
+                                                          C.byref(t), _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+                           "mst_encoder_forward_train_in")
             if phase in (1, 2):
                 yield "sum", self.stats_view(phase, B, Fr)
         return emb, out
@@ -332,13 +345,13 @@ class HipEncoder:
         """conv1 weight gradient (n_sub, 32, 8, 7, 7) from the d(conv1 output) that `backward_apply(1, ..., inplace=True)`
         left in the workspace (`mst_encoder_train_conv1_wgrad`)."""
         L = _lib.lib()
-        dw = torch.empty(self.n_sub, 32, 8, 7, 7, device=logmel.device)
+        lin, keep, _, dev = self._logmel_in(logmel)   # the SAME log-mel (layout included) the forward pass read
+        dw = torch.empty(self.n_sub, 32, 8, 7, 7, device=dev)
         need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
-        lm = logmel.contiguous().float()
-        with torch.cuda.device(lm.device):
-            _lib.check(L.mst_encoder_train_conv1_wgrad(self._h, _lib.dptr(lm), B, frames, _lib.dptr(dw),
-                                                       _lib.dptr(self._ws_train), need, _lib.stream_ptr(lm.device)),
-                       "mst_encoder_train_conv1_wgrad")
+        with torch.cuda.device(dev):
+            _lib.check(L.mst_encoder_train_conv1_wgrad_in(self._h, C.byref(lin), B, frames, _lib.dptr(dw),
+                                                          _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+                       "mst_encoder_train_conv1_wgrad_in")
         return dw
 
     def conv2_dgrad(self, dy2, B, frames, mask=None, drop_p=0.0):
@@ -498,7 +511,10 @@ class _HipTrunk(torch.autograd.Function):
         sub-bands -- the storage the per-band Parameters are views of (MixingStyleEncoder._trunk_flat), so no stack kernels run;
         params: those Parameters themselves, family-major, only so that autograd routes the gradients to them (the backward
         returns views of the stacked gradients, which AccumulateGrad adopts without a copy when .grad is None)."""
-        B, _, M, Fr = logmel.shape
+        if isinstance(logmel, LogMel):
+            B, Fr = logmel.B, logmel.frames
+        else:
+            B, _, M, Fr = logmel.shape
         trunk = tuple(b.clone() for b in flat)   # this pass's parameter snapshot (8 small copies; an optimizer step or another
         #                                          pass may rewrite the live storage before this pass's backward runs)
         ctx.n_sub = flat[0].shape[0]
@@ -520,14 +536,22 @@ class _HipTrunk(torch.autograd.Function):
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync, ctx.reducer = enc, drop_p, (B, Fr), sync, reducer
         ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode
         # (the workspace rides with the saved tensors: autograd releases it with them after a backward that does not retain the graph)
-        ctx.save_for_backward(logmel, t["pool1"], mask, enc._ws_train, *trunk)
+        if isinstance(logmel, LogMel):   # stage A's float16 planes: kept for conv1's weight gradient as they are
+            ctx.lm_layout = logmel.layout
+            ctx.save_for_backward(logmel.data, logmel.lo, t["pool1"], mask, enc._ws_train, *trunk)
+        else:
+            ctx.lm_layout = None
+            ctx.save_for_backward(logmel, None, t["pool1"], mask, enc._ws_train, *trunk)
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
         return t["pool_in"], t["bn1"], t["bn2"]
 
     @staticmethod
     def backward(ctx, dpool_in, _d1, _d2):
         enc, (B, Fr) = ctx.enc, ctx.dims
-        logmel, p1, mask, ws, *trunk = ctx.saved_tensors
+        logmel, lm_lo, p1, mask, ws, *trunk = ctx.saved_tensors
+        dev = logmel.device
+        if ctx.lm_layout is not None:
+            logmel = LogMel(ctx.lm_layout, logmel, lm_lo)
         if getattr(ctx, "consumed", False):
             raise RuntimeError("HIP training trunk (fp32 mode): second backward() through the same forward pass -- the fp32 kernels "
                                "turn the saved convolution outputs into their gradients IN PLACE; run the forward again, or use "
@@ -547,12 +571,12 @@ class _HipTrunk(torch.autograd.Function):
                 e.record()
                 marks.append((name, e))
         mark("start")
-        dfilm = torch.zeros(B, ns * 192, device=logmel.device)
+        dfilm = torch.zeros(B, ns * 192, device=dev)
         sync = ctx.sync
         dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr, sync=sync)
         mark("apply_bwd2")
         gw2 = enc.conv2_wgrad(p1, B, Fr)          # weight gradient on dy2 in accumulator order
-        gb2 = torch.zeros(ns, 64, device=logmel.device)   # exactly 0 in front of a batch-statistics BatchNorm
+        gb2 = torch.zeros(ns, 64, device=dev)   # exactly 0 in front of a batch-statistics BatchNorm
         mark("conv2_wgrad")
         dbn2w, dbn2b = dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous()
         reducer = ctx.reducer
@@ -563,7 +587,7 @@ class _HipTrunk(torch.autograd.Function):
         _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
         mark("apply_bwd1")
         gw1 = enc.conv1_wgrad(logmel, B, Fr)
-        gb1 = torch.zeros(ns, 32, device=logmel.device)
+        gb1 = torch.zeros(ns, 32, device=dev)
         mark("conv1_wgrad")
         if _TRAIN_TIMING:
             torch.cuda.synchronize()
@@ -651,25 +675,9 @@ class MixingStyleEncoder(nn.Module):
     def _forward_train_hip(self, logmel, mixing_features):
         """Training forward with the trunk in libmst.so (see _HipTrunk); FiLM MLP and attention head stay torch modules."""
         ae, fe = self.audio_encoder, self.film_encoder
-        if self._hip_train is None:
-            self._hip_train = HipEncoder(self, "fp32")
-        enc = self._hip_train
-        if self.train_precision not in ("fp32", "f16", "f16x3", "auto"):
-            raise ValueError("train_precision must be 'fp32', 'f16', 'f16x3' or 'auto'")
-        want = self.train_precision
-        if want == "auto":
-            amp16 = torch.is_autocast_enabled() and (torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype")
-                                                     else torch.get_autocast_gpu_dtype()) == torch.float16
-            want = "f16" if amp16 else "fp32"
-        if want != "fp32" and enc.sub != 2 and ae.split_size % 2:
-            why = f"split_size={ae.split_size}: the f16 training kernels need an even split_size; the trunk stays fp32"
-            if self.train_precision != "auto":
-                raise RuntimeError(f"MixingStyleEncoder.train_precision='{self.train_precision}': " + why)
-            if why not in self._warned:
-                self._warned.add(why)
-                warnings.warn("MixingStyleEncoder under autocast: " + why, RuntimeWarning, stacklevel=3)
-            want = "fp32"
-        enc.set_train_precision(want)
+        enc = self._train_encoder()
+        if isinstance(logmel, LogMel) and logmel.layout != enc.train_layout():
+            logmel = logmel.to_reference()   # (a caller's own LogMel in a layout this precision mode does not read)
         cn = ae.subnet_cnns
         trunk_flat, trunk_params = self._trunk_flat()
         flat = fe.film_head(fe.feature_mlp(mixing_features))
@@ -684,7 +692,7 @@ class MixingStyleEncoder(nn.Module):
         pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, trunk_flat, float(p), sync, getattr(self, "_grad_reducer", None),
                                             *trunk_params)
         with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
-            B, Fr = logmel.shape[0], logmel.shape[-1]
+            B, Fr = (logmel.B, logmel.frames) if isinstance(logmel, LogMel) else (logmel.shape[0], logmel.shape[-1])
             if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different
                 B = enc.stats_view(1, B, Fr)[-2].to(torch.float64)   # numbers of clips); a device scalar: no host sync
             for stat, name, n in ((bn1, "bn1", B * (ae.split_size * Fr)), (bn2, "bn2", B * ((ae.split_size // enc.sub) * (Fr // 5)))):
@@ -707,23 +715,52 @@ class MixingStyleEncoder(nn.Module):
         x = F.dropout(pool_in, cn[0].dropout2.p, self.training)
         return ae.attention_pooling(x)
 
+    def _train_encoder(self):
+        """The training-side encoder handle with the precision mode this call resolves to (train_precision; "auto" = f16 inside
+        torch.autocast(float16), fp32 otherwise)."""
+        ae = self.audio_encoder
+        if self._hip_train is None:
+            self._hip_train = HipEncoder(self, "fp32")
+        enc = self._hip_train
+        if self.train_precision not in ("fp32", "f16", "f16x3", "auto"):
+            raise ValueError("train_precision must be 'fp32', 'f16', 'f16x3' or 'auto'")
+        want = self.train_precision
+        if want == "auto":
+            amp16 = torch.is_autocast_enabled() and (torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype")
+                                                     else torch.get_autocast_gpu_dtype()) == torch.float16
+            want = "f16" if amp16 else "fp32"
+        if want != "fp32" and enc.sub != 2 and ae.split_size % 2:
+            why = f"split_size={ae.split_size}: the f16 training kernels need an even split_size; the trunk stays fp32"
+            if self.train_precision != "auto":
+                raise RuntimeError(f"MixingStyleEncoder.train_precision='{self.train_precision}': " + why)
+            if why not in self._warned:
+                self._warned.add(why)
+                warnings.warn("MixingStyleEncoder under autocast: " + why, RuntimeWarning, stacklevel=3)
+            want = "fp32"
+        enc.set_train_precision(want)
+        return enc
+
     def _hip_trunk_refusal(self, logmel):
         """Why the hand-written training trunk cannot take this call (None = it can)."""
         if self.audio_encoder.split_size // 10 not in (1, 2):
             return f"split_size={self.audio_encoder.split_size}: the training kernels cover first-pool heights 1 and 2"
-        if not logmel.is_cuda:
+        cm = isinstance(logmel, LogMel)
+        frames = logmel.frames if cm else logmel.shape[-1]
+        if not (logmel.data if cm else logmel).is_cuda:
             return "log-mel is not on the GPU"
-        if logmel.shape[-1] < 20:
-            return f"{logmel.shape[-1]} frames < 20"
-        if logmel.dtype != torch.float32 or self.film_encoder.film_head.weight.dtype != torch.float32:
+        if frames < 20:
+            return f"{frames} frames < 20"
+        if (not cm and logmel.dtype != torch.float32) or self.film_encoder.film_head.weight.dtype != torch.float32:
             return f"non-fp32 tensors (log-mel {logmel.dtype}, parameters {self.film_encoder.film_head.weight.dtype})"
         return None
 
     def forward_from_logmel(self, logmel, mixing_features):
         auto = self._needs_autograd(mixing_features)
-        if isinstance(logmel, LogMel) and not (self.encoder_backend == "hip" and not auto and not self.training):
-            logmel = logmel.to_reference()   # only the eval forward in libmst.so reads the channel-minor layouts
-        if self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict"):
+        hip_train = self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict")
+        if isinstance(logmel, LogMel) and not (self.encoder_backend == "hip" and not auto and not self.training) and \
+                not (hip_train and self._hip_trunk_refusal(logmel) is None):
+            logmel = logmel.to_reference()   # only the eval forward and the float16 training trunk in libmst.so read channel-minor layouts
+        if hip_train:
             why = self._hip_trunk_refusal(logmel)
             if why is None:
                 return self._forward_train_hip(logmel, mixing_features)
@@ -758,11 +795,19 @@ class MixingStyleEncoder(nn.Module):
         has_feats = bins is not None and (bins == 0 or bins <= self.audio_encoder.n_mels)
         plan = pre.plan(bins if has_feats else 0)
         # the eval forward in libmst.so takes the log-mel in its internal channel-minor layout when stage A can write it
-        # (whole-line stores there, 256-byte runs / ready-made float16 operands for conv1); every other path -- training,
-        # the PyTorch backend -- gets the reference's (B, 8, n_mels, frames) tensor
+        # (whole-line stores there, 256-byte runs / ready-made float16 operands for conv1), and so does the hand-written
+        # training trunk in its float16 modes; every other path -- fp32 training, the PyTorch backend -- gets the reference's
+        # (B, 8, n_mels, frames) tensor
         layout = _lib.LOGMEL_REF
-        if self.encoder_backend == "hip" and not self.training and not self._needs_autograd(mixing_features):
+        auto = self._needs_autograd(mixing_features)
+        if self.encoder_backend == "hip" and not self.training and not auto:
             want = self.hip_encoder().preferred_layout()
+            if plan.supports_layout(want):
+                layout = want
+        elif self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict") and \
+                self.audio_encoder.split_size // 10 in (1, 2):
+            # the float16 training trunk reads stage A's float16 planes (conv1 forward and its weight gradient)
+            want = self._train_encoder().train_layout()
             if plan.supports_layout(want):
                 layout = want
         with torch.no_grad():

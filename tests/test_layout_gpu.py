@@ -161,3 +161,85 @@ def test_full_size_batch_properties_channel_minor():
     fr = torch.arange(0, plan.frames(T), 97, device="cuda")
     assert torch.equal(cm.data[:2].index_select(1, fr), ref.permute(0, 3, 2, 1).index_select(1, fr))
     assert np.isfinite(cm.data.float().sum().item())
+
+
+@pytest.mark.parametrize("precision", ["f16", "f16x3"])
+@pytest.mark.parametrize("cfgname,T,B", [("default", 44100 + 13, 5), ("baseline_sh", 66150, 3)])
+def test_training_step_is_bit_identical_from_stage_a_float16_planes(cfgname, T, B, precision):
+    """The float16 training trunk reads stage A's MST_LOGMEL_CM16 planes directly (conv1 forward and conv1's weight gradient:
+    `mst_encoder_forward_train_in`, `mst_encoder_train_conv1_wgrad_in`).  The planes hold exactly the float16 roundings the
+    reference-layout kernels derive while staging, and the arithmetic order is the same, so the whole step -- loss, every
+    parameter gradient, the running statistics -- is BIT-IDENTICAL to the step from the reference-layout tensor: the training
+    parity tests of test_encoder_gpu.py (which feed the reference layout) carry over.  B = 5 / 3: a ragged last clip group of
+    the weight gradient's 8-clip K blocks.  The module's own forward must pick the float16 planes by itself."""
+    import copy
+    from mst_amd import _lib
+    from test_encoder_gpu import build_model
+    cfg = cases.CFG_DEFAULT if cfgname == "default" else cases.CFG_BASELINE_SH
+    base, _ = build_model(cfg)
+    d = _stems(B, T, seed=2)
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(B, 64, generator=g).cuda()
+    R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
+    runs, layouts = [], []
+    for how in ("reference", "planes", "module"):
+        m = copy.deepcopy(base).train()
+        m.train_backend, m.train_precision = "hip-strict", precision
+        plan = m.audio_encoder.mel_preprocessor.plan(0)
+        torch.manual_seed(77)   # the Dropout seed
+        if how == "reference":
+            lm, _ = plan.forward_stems(d, True, False)
+            emb = m.forward_from_logmel(lm, feats)
+        elif how == "planes":
+            assert m._train_encoder().train_layout() == _lib.LOGMEL_CM16 and plan.supports_layout(_lib.LOGMEL_CM16)
+            lm, _ = plan.forward_stems(d, True, False, _lib.LOGMEL_CM16, want_absmax=True)
+            emb = m.forward_from_logmel(lm, feats)
+        else:
+            orig = plan.forward_stems
+
+            def spy(*a, **k):
+                layouts.append(a[3] if len(a) > 3 else k.get("layout", _lib.LOGMEL_REF))
+                return orig(*a, **k)
+            plan.forward_stems = spy
+            emb = m(d, feats)
+        loss = (emb * R).sum()
+        loss.backward()
+        runs.append((loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()},
+                     {n: b.detach().clone() for n, b in m.named_buffers() if "running" in n}))
+    assert layouts == [_lib.LOGMEL_CM16], layouts
+    l0, g0, s0 = runs[0]
+    assert np.isfinite(l0.item()) and all(torch.isfinite(v).all() for v in g0.values())
+    for l1, g1, s1 in runs[1:]:
+        assert torch.equal(l0, l1), (l0.item(), l1.item())
+        diff = [n for n in g0 if not torch.equal(g0[n], g1[n])]
+        assert not diff, f"{len(diff)} gradient tensors differ, e.g. {diff[:3]}"
+        assert all(torch.equal(s0[n], s1[n]) for n in s0)
+
+
+def test_fp32_training_keeps_the_reference_layout_and_converts_a_given_logmel():
+    """The fp32 training kernels read the reference layout: the module does not ask stage A for planes, and a LogMel a caller
+    passes anyway is converted back (same values), not refused."""
+    import copy
+    from mst_amd import _lib
+    from test_encoder_gpu import build_model
+    cfg = cases.CFG_DEFAULT
+    base, _ = build_model(cfg)
+    B, T = 2, 44100
+    d = _stems(B, T, seed=4)
+    feats = torch.randn(B, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    outs = []
+    for how in ("reference", "cm32"):
+        m = copy.deepcopy(base).train()
+        m.train_backend, m.train_precision = "hip-strict", "fp32"
+        assert m._train_encoder().train_layout() == _lib.LOGMEL_REF
+        plan = m.audio_encoder.mel_preprocessor.plan(0)
+        lm, _ = plan.forward_stems(d, True, False, _lib.LOGMEL_REF if how == "reference" else _lib.LOGMEL_CM32)
+        torch.manual_seed(3)
+        emb = m.forward_from_logmel(lm, feats)
+        emb.sum().backward()
+        outs.append((emb.detach().clone(), m.film_encoder.film_head.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    enc = copy.deepcopy(base).train()._train_encoder()
+    lm16, _ = base.audio_encoder.mel_preprocessor.plan(0).forward_stems(d, True, False, _lib.LOGMEL_CM16, want_absmax=True)
+    with pytest.raises(_lib.MstError, match="layout"):
+        enc.forward_train(lm16, feats=feats)   # straight at the C entry: the fp32 mode refuses the float16 planes
