@@ -302,11 +302,14 @@ def main():
             from mst_amd.dist import GradientReducer
             reducer = GradientReducer(model)
 
+        # the reference trainer's call (src/train.py:253): the Dataset's deferred feature rows + the stems; ONE stage-A launch
+        # inside model.forward yields the features and the log-mel in the layout the training trunk of this precision reads
+        from mst_amd.mixing_utils import deferred_features
+        deferred = torch.stack([deferred_features(model.film_encoder.feature_dim)] * B).to(dev)
+
         def train_step():
-            with torch.no_grad():
-                feats, logmel = fe.features_and_logmel(stems)
             with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
-                emb = model.forward_from_logmel(logmel, feats)
+                emb = model(stems, deferred)
                 loss = crit_t(emb, labels)
             opt.zero_grad(set_to_none=True)
             (scaler.scale(loss) if amp else loss).backward()

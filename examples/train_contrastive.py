@@ -23,7 +23,7 @@ from torch.utils.data import DataLoader
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mst_amd import ingest  # noqa: E402
 from mst_amd.loss import InfoNCELoss  # noqa: E402
-from mst_amd.mixing_utils import MixingFeatureExtractor  # noqa: E402
+from mst_amd.mixing_utils import deferred_features  # noqa: E402
 from mst_amd.model import MixingStyleEncoder  # noqa: E402
 from mst_amd.synth import synth_clip  # noqa: E402
 
@@ -64,7 +64,7 @@ def main(argv=None):
     model = MixingStyleEncoder(sr, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).to(dev).train()
     model.train_backend = a.train_backend
     model.train_precision = a.train_precision
-    fe = MixingFeatureExtractor(sr, 1024, 256, 128)
+    deferred = torch.stack([deferred_features(64)] * (2 * a.batch_size)).to(dev)   # what the Dataset's feature slot carries
     crit = InfoNCELoss(0.1)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr)
     stager = ingest.DeviceStager((2 * a.batch_size, 8, ds.clip_samples), torch.int16, dev)
@@ -81,10 +81,10 @@ def main(argv=None):
             it = iter(dl)
             stems, labels, _ = next(it)
         nxt, lab = stager.submit(stems), labels
-        with torch.no_grad():                  # stage A: the waveform needs no gradient
-            feats, logmel = fe.features_and_logmel(ingest.stems_views(x))
+        # the reference trainer's call (src/train.py:253) with the Dataset's deferred feature rows: ONE stage-A launch inside
+        # yields the features and the log-mel, in the layout the training trunk reads
+        emb = model(ingest.stems_views(x), deferred[:x.shape[0]])
         stager.release(fut)
-        emb = model.forward_from_logmel(logmel, feats)
         loss = crit(emb, cur_lab)
         opt.zero_grad(set_to_none=True)
         loss.backward()

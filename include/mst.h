@@ -309,6 +309,9 @@ int mst_encoder_train_conv1_wgrad_in(const mst_encoder* enc, const mst_logmel_in
 /* conv2 weight gradient, same scheme (dy of layer 2 is always left in the workspace in accumulator order by
  * mst_encoder_train_backward_apply(layer 2), next to the NCHW copy it returns).
  * pool1: dev [B][n_sub][32][H1][W1], the (dropped-out) input of conv2 as the training forward produced it.
+ *        NULL in the float16 training modes: the operand is taken from the float16 pool1 planes the training forward left in
+ *        the workspace (the bits the fp32 tensor would be rounded to); mst_encoder_forward_train then writes the fp32 pool1
+ *        only when taps->pool1 asks for it.
  * dw:    out dev [n_sub][64][32][7][7] (zeroed here).                                                           */
 int mst_encoder_train_conv2_wgrad(const mst_encoder* enc, const float* pool1, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream);

@@ -2091,7 +2091,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
           keep = p.mask[o] != 0;
         }
         const float v = (p.mask_out || p.mask) ? (keep ? m * p.mask_scale : 0.f) : m;
-        p.out[o] = v;
+        if (p.out) p.out[o] = v;   // (NULL in the float16 modes unless the caller asked for the fp32 tensor)
         if (p.out_h16) {
           const size_t o16 = ((((size_t)clip * p.nsub + band) * p.out_rows + prow) * p.out_cols + pc) * 32 + ch;
           const float vs = v * p.f16_scale[((size_t)clip * p.nsub + band) * 2];
@@ -3539,6 +3539,7 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
     ApplyParams ap{y1, e->cfg.split_size, aff1, pool1, taps ? taps->drop1_mask : nullptr, taps ? taps->drop1_scale : 1.f,
                    B, ns, T.tr1, T.tc1, e->H1, L.W1, (long long)B * ns * T.tr1 * T.tc1 * 2 * 64, nullptr, nullptr, frames};
     if (train_fwd16(e)) {   // range scale of conv2's f16 operand: one power of two per band from a bound on the pooled values
+      if (!(taps && taps->pool1)) ap.out = nullptr;   // conv2 and its weight gradient read the float16 planes: fp32 pool1 only on request
       unsigned* xmax = reinterpret_cast<unsigned*>(ws + T.t_xmax);   // (computed in front of conv1)
       float* fsc = reinterpret_cast<float*>(ws + T.t_f16scale);
       hipLaunchKernelGGL(f16_scale_band_kernel, dim3(ns), dim3(64), 0, st, aff1, e->w1norm, xmax, e->c1b,
@@ -3915,7 +3916,10 @@ int mst_encoder_train_conv1_wgrad_in(const mst_encoder* e, const mst_logmel_in* 
 
 int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int B, int frames, float* dw,
                                   void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(e && pool1 && dw, "mst_encoder_train_conv2_wgrad: NULL argument");
+  MST_REQUIRE(e && dw, "mst_encoder_train_conv2_wgrad: NULL argument");
+  // pool1 == NULL (float16 training modes only): conv2's operand is taken from the float16 pool1 planes the training forward left
+  // in the workspace -- the bits the fp32 tensor would be rounded to -- so the forward need not write the fp32 pool1 at all
+  MST_REQUIRE(pool1 || train_bwd16(e), "mst_encoder_train_conv2_wgrad: pool1 == NULL needs a float16 training mode");
   MST_REQUIRE(B > 0 && frames >= 20, "mst_encoder_train_conv2_wgrad: bad arguments");
   const TrainLayout T = train_layout(e, B, frames);
   const WsLayout& L = T.base;
@@ -3937,7 +3941,9 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
   if (train_bwd16(e)) {
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
     WgradF16Params fp{pool1, reinterpret_cast<const h16x8*>(ws + T.t_dyg2), dwa, reinterpret_cast<const float*>(ws + T.t_f16scale),
-                      B, ns, T.tr2, T.tc2, e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1};
+                      B, ns, T.tr2, T.tc2, e->H1, L.W1, e->H1 * L.W1, 32 * e->H1 * L.W1, (long long)ns * 32 * e->H1 * L.W1,
+                      nullptr, 0, 0};
+    if (!pool1) fp.x = ws + T.t_pool1_h16, fp.x_lo = ws + T.t_pool1_l16;   // (in_clipstride = elements per clip in either form)
     const long long items = (long long)ns * ((B + 7) / 8) * T.tr2 * T.tc2;
     constexpr size_t lds1 = (size_t)(8 * 14 * 14 + 4 * 16 * 64) * 16, lds3 = (size_t)(2 * 8 * 14 * 14 + 4 * 8 * 2 * 64) * 16;
     static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
@@ -3947,10 +3953,19 @@ int mst_encoder_train_conv2_wgrad(const mst_encoder* e, const float* pool1, int 
       if (err == hipSuccess)
         err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2, 3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2, 1, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      if (err == hipSuccess)
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f16_kernel<2, 3, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
       if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 wgrad (f16) attribute failed: %s", hipGetErrorString(err));
     }
     const dim3 gw((int)std::min<long long>(e->num_cus & ~3, 4 * items));
-    if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<2, 3>), gw, dim3(kConvThreads), lds3, st, fp);
+    if (!pool1) {
+      if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<2, 3, 3>), gw, dim3(kConvThreads), lds3, st, fp);
+      else hipLaunchKernelGGL((wgrad_f16_kernel<2, 1, 3>), gw, dim3(kConvThreads), lds1, st, fp);
+    } else if (e->train_f16 == 2) hipLaunchKernelGGL((wgrad_f16_kernel<2, 3>), gw, dim3(kConvThreads), lds3, st, fp);
     else hipLaunchKernelGGL((wgrad_f16_kernel<2, 1>), gw, dim3(kConvThreads), lds1, st, fp);
   } else {
     hipLaunchKernelGGL(conv2_wgrad_kernel, dim3(g), dim3(kConvThreads), 0, st, wp);

@@ -243,11 +243,12 @@ class HipEncoder:
         _lib.check(_lib.lib().mst_encoder_train_scale_buffer(self._h, B, frames, C.byref(off)), "mst_encoder_train_scale_buffer")
         return self._ws_view(off.value, 4, torch.int32)
 
-    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, sync=None, drop1_seed=None):
+    def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, sync=None, drop1_seed=None,
+                      want_pool1=True):
         """`forward_train_steps` run to completion; `sync` (an object with `.world`, `.sum(int64 tensor)`, `.max(int32 tensor)`,
         e.g. DistSync) adds the ranks' BatchNorm statistics between the phases; None = this process only."""
         steps = self.forward_train_steps(logmel, feats, film, head, drop1_mask, drop1_p, sync.world if sync is not None else 0,
-                                         drop1_seed)
+                                         drop1_seed, want_pool1)
         try:
             while True:
                 kind, view = next(steps)
@@ -271,7 +272,7 @@ class HipEncoder:
         return lay if _lib.lib().mst_encoder_train_layout_supported(self._h, lay) else _lib.LOGMEL_REF
 
     def forward_train_steps(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, world=0,
-                            drop1_seed=None):
+                            drop1_seed=None, want_pool1=True):
         """Generator form of the train-mode forward.  world = 0: one call of `mst_encoder_forward_train`, nothing is yielded.
         world >= 1: the three phases of include/mst.h; after phase 1 and 2 it yields ("sum", int64 view of that layer's
         statistics accumulators), which the caller must all-reduce (SUM) over its `world` ranks before resuming.
@@ -281,7 +282,9 @@ class HipEncoder:
         head=False stops at pool_in (emb is None).  drop1_mask: uint8 keep-mask shaped like pool1 (Dropout after the
         first pooling); or drop1_seed (int) with drop1_p > 0: the kernel draws the mask itself (Philox, a pure function of
         (seed, element)) and returns it as taps["drop1_mask"].  Returns (emb, taps) with taps = film, pool1, pool_in, bn1, bn2 ((n_sub, C, 2): batch mean and
-        1/sqrt(biased var + eps)).  The raw conv outputs stay in the workspace for `backward_apply`."""
+        1/sqrt(biased var + eps)).  The raw conv outputs stay in the workspace for `backward_apply`.
+        want_pool1=False (float16 training modes): the fp32 pool1 is not written -- conv2 and its weight gradient read the float16
+        planes the pooling epilogue leaves in the workspace (`conv2_wgrad(None, ...)`)."""
         lin, keep, (B, Fr), dev = self._logmel_in(logmel)
         L = _lib.lib()
         need = L.mst_encoder_train_workspace_bytes(self._h, B, Fr)
@@ -293,19 +296,22 @@ class HipEncoder:
             self._ws_train.fill_(255)
         emb = torch.empty(B, self.embed_dim, dtype=torch.float32, device=dev) if head else None
         W1 = Fr // 5
+        p1_shape = (B, self.n_sub, 32, self.split // max(1, self.split // 10), W1)
+        if not want_pool1 and not self.train_f16:
+            raise _lib.MstError("forward_train(want_pool1=False) needs a float16 training mode (the fp32 conv2 reads the fp32 pool1)")
         out = {"film": torch.empty(B, self.n_sub * 192, device=dev),
-               "pool1": torch.empty(B, self.n_sub, 32, self.split // max(1, self.split // 10), W1, device=dev),
+               "pool1": torch.empty(p1_shape, device=dev) if want_pool1 else None,
                "pool_in": torch.empty(B, 64 * self.n_sub * self.freq_dim, W1 // 4, device=dev),
                "bn1": torch.empty(self.n_sub, 32, 2, device=dev), "bn2": torch.empty(self.n_sub, 64, 2, device=dev)}
         film_c = film.detach().contiguous().float() if film is not None else None
         feats_c = feats.contiguous().float() if feats is not None else None
         mask_c = drop1_mask.contiguous() if drop1_mask is not None else None
         if mask_c is not None:
-            assert mask_c.dtype == torch.uint8 and tuple(mask_c.shape) == tuple(out["pool1"].shape)
+            assert mask_c.dtype == torch.uint8 and tuple(mask_c.shape) == p1_shape
         mask_out = None
         if drop1_seed is not None and drop1_p > 0.0:
             assert mask_c is None, "pass a mask OR a seed"
-            mask_out = out["drop1_mask"] = torch.empty(out["pool1"].shape, dtype=torch.uint8, device=dev)
+            mask_out = out["drop1_mask"] = torch.empty(p1_shape, dtype=torch.uint8, device=dev)
         for phase in ((0,) if world == 0 else (1, 2, 3)):
             t = _lib.EncoderTrainTaps(*[_lib.dptr(out[k]) for k in ("film", "pool1", "pool_in", "bn1", "bn2")],
                                       _lib.dptr(film_c), _lib.dptr(mask_c), 1.0 / (1.0 - drop1_p) if mask_c is not None else 1.0,
@@ -367,14 +373,16 @@ class HipEncoder:
         return out
 
     def conv2_wgrad(self, pool1, B, frames):
-        """conv2 weight gradient (n_sub, 64, 32, 7, 7) from the accumulator-order d(conv2 output) in the workspace."""
+        """conv2 weight gradient (n_sub, 64, 32, 7, 7) from the accumulator-order d(conv2 output) in the workspace.
+        pool1 None (float16 training modes): the operand is the float16 pool1 the forward pass left in the workspace."""
         L = _lib.lib()
-        dw = torch.empty(self.n_sub, 64, 32, 7, 7, device=pool1.device)
+        dev = self._ws_train.device
+        dw = torch.empty(self.n_sub, 64, 32, 7, 7, device=dev)
         need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
-        p1 = pool1.contiguous().float()
-        with torch.cuda.device(p1.device):
+        p1 = pool1.contiguous().float() if pool1 is not None else None
+        with torch.cuda.device(dev):
             _lib.check(L.mst_encoder_train_conv2_wgrad(self._h, _lib.dptr(p1), B, frames, _lib.dptr(dw),
-                                                       _lib.dptr(self._ws_train), need, _lib.stream_ptr(p1.device)),
+                                                       _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
                        "mst_encoder_train_conv2_wgrad")
         return dw
 
@@ -531,7 +539,9 @@ class _HipTrunk(torch.autograd.Function):
         # plain training loop allocates nothing): several forward passes may be alive at once -- retained graphs, two
         # forwards before one backward -- each backward finds its activations in the workspace its context holds
         enc._ws_train = None
-        _, t = enc.forward_train(logmel, film=film, head=False, drop1_p=drop_p, sync=sync, drop1_seed=seed)
+        # (float16 modes: conv2 and its weight gradient read the float16 pool1 planes in the workspace -- no fp32 pool1 tensor)
+        _, t = enc.forward_train(logmel, film=film, head=False, drop1_p=drop_p, sync=sync, drop1_seed=seed,
+                                 want_pool1=not enc.train_f16)
         mask = t.get("drop1_mask")
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync, ctx.reducer = enc, drop_p, (B, Fr), sync, reducer
         ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode

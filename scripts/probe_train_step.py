@@ -20,10 +20,12 @@ x = synth_batch(B, T, device="cuda")
 stems = {s: x[:, 2 * i:2 * i + 2] for i, s in enumerate(("vocals", "bass", "drums", "other"))}
 labels = torch.arange(B, device="cuda") // 3
 
+from mst_amd.mixing_utils import deferred_features
+deferred = torch.stack([deferred_features(64)] * B).cuda()
+
+
 def step():
-    with torch.no_grad():
-        feats, logmel = fe.features_and_logmel(stems)
-    emb = model.forward_from_logmel(logmel, feats)
+    emb = model(stems, deferred)   # the trainer's call: one stage-A launch inside yields features + log-mel
     loss = crit(emb, labels)
     opt.zero_grad(set_to_none=True)
     loss.backward()

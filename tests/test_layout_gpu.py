@@ -243,3 +243,39 @@ def test_fp32_training_keeps_the_reference_layout_and_converts_a_given_logmel():
     lm16, _ = base.audio_encoder.mel_preprocessor.plan(0).forward_stems(d, True, False, _lib.LOGMEL_CM16, want_absmax=True)
     with pytest.raises(_lib.MstError, match="layout"):
         enc.forward_train(lm16, feats=feats)   # straight at the C entry: the fp32 mode refuses the float16 planes
+
+
+@pytest.mark.parametrize("precision", ["f16", "f16x3"])
+def test_conv2_weight_gradient_from_the_float16_pool1_planes(precision):
+    """`mst_encoder_train_conv2_wgrad(pool1 = NULL)` (float16 training modes): conv2's weight gradient reads the float16
+    pool1 planes the pooling epilogue left in the workspace instead of rounding the fp32 tensor again -- the same bits, so the
+    gradient is bit-identical -- and a forward pass that is not asked for the fp32 pool1 does not produce it."""
+    from test_encoder_gpu import build_model
+    cfg = cases.CFG_DEFAULT
+    m, _ = build_model(cfg)
+    enc = m.train()._train_encoder()
+    enc.set_train_precision(precision)
+    flat, _ = m._trunk_flat()
+    enc.update_trunk_params(*flat)
+    B, T = 3, 44100
+    plan = m.audio_encoder.mel_preprocessor.plan(0)
+    lm, _ = plan.forward_stems(_stems(B, T, seed=6), True, False)
+    g = torch.Generator().manual_seed(8)
+    film = (torch.randn(B, enc.n_sub * 192, generator=g) * 0.3 + 1.0).cuda()
+    Fr = lm.shape[-1]
+    grads = []
+    for want in (True, False):
+        enc._ws_train = None
+        _, t = enc.forward_train(lm, film=film, head=False, drop1_p=0.3, drop1_seed=5, want_pool1=want)
+        assert (t["pool1"] is not None) == want
+        dp = torch.randn(t["pool_in"].shape, generator=g).cuda() if not grads else dp   # noqa: F821
+        dfilm = torch.zeros(B, enc.n_sub * 192, device="cuda")
+        enc.backward_apply(2, dp, dfilm, B, Fr)
+        grads.append(enc.conv2_wgrad(t["pool1"], B, Fr))
+    torch.cuda.synchronize()
+    assert torch.isfinite(grads[0]).all() and grads[0].abs().max() > 0
+    assert torch.equal(grads[0], grads[1])
+    enc.set_train_precision("fp32")
+    enc._ws_train = None
+    with pytest.raises(Exception, match="float16"):
+        enc.forward_train(lm, film=film, head=False, want_pool1=False)
