@@ -203,22 +203,30 @@ struct ConvParams {
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // one lane-unit (NV accumulator slots) of the raw convolution output: fp32, or (y_scale != NULL) float16 times the band's scale
+// Two orders of a unit's NV / 4 four-slot vectors inside its block of 64 lane-units (one (tile, N-tile)):
+//   lane-major (fp32 training mode): vector t of lane l at [64-block][l][t] -- the order the fp32 weight-gradient kernels stage;
+//   t-major    (float16 training modes, `tmajor`): [64-block][t][l] -- a wave's access to vector t is one contiguous run (512 B of
+//   float16, 1 KB of fp32) instead of 64 pieces 40 / 80 bytes apart, for the convolution's stores and for the three
+//   element-wise passes that read the tensor back.
+__device__ __forceinline__ size_t yvec(size_t unit, int t, int nvec, bool tmajor) {
+  return tmajor ? (unit & ~(size_t)63) * nvec + (size_t)t * 64 + (unit & 63) : unit * nvec + t;
+}
 template <int NV>
-__device__ __forceinline__ void load_unit(const void* yraw, const float* y_scale, int band, size_t unit, float (&v)[NV]) {
+__device__ __forceinline__ void load_unit(const void* yraw, const float* y_scale, int band, size_t unit, float (&v)[NV], bool tmajor) {
   if (y_scale) {   // kernel-uniform
     const float inv = y_scale[band * 2 + 1];
-    const h16x4* s = reinterpret_cast<const h16x4*>(yraw) + unit * (NV / 4);
+    const h16x4* s = reinterpret_cast<const h16x4*>(yraw);
 #pragma unroll
     for (int t = 0; t < NV / 4; ++t) {
-      const h16x4 q = s[t];
+      const h16x4 q = s[yvec(unit, t, NV / 4, tmajor)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * t + r] = (float)q[r] * inv;
     }
   } else {
-    const f32x4* s = reinterpret_cast<const f32x4*>(yraw) + unit * (NV / 4);
+    const f32x4* s = reinterpret_cast<const f32x4*>(yraw);
 #pragma unroll
     for (int t = 0; t < NV / 4; ++t) {
-      const f32x4 q = s[t];
+      const f32x4 q = s[yvec(unit, t, NV / 4, tmajor)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
     }
@@ -1116,8 +1124,8 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
             const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
             if (col < p.raw_cols) ps += v[r], pq = fmaf(v[r], v[r], pq);
           }
-          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
-          else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
+          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[yvec(unit, t, MT, true)] = h;   // t-major: whole-line stores
+          else reinterpret_cast<f32x4*>(p.yraw)[yvec(unit, t, MT, true)] = v;
         }
         st[n][0] += (double)ps, st[n][1] += (double)pq;
       }
@@ -1645,8 +1653,8 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
             const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
             if (row < p.raw_rows && col < p.raw_cols) ps += v[r], pq = fmaf(v[r], v[r], pq);
           }
-          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[unit * MT + t] = h;
-          else reinterpret_cast<f32x4*>(p.yraw)[unit * MT + t] = v;
+          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[yvec(unit, t, MT, true)] = h;   // t-major: whole-line stores
+          else reinterpret_cast<f32x4*>(p.yraw)[yvec(unit, t, MT, true)] = v;
         }
         st[n][0] += (double)ps, st[n][1] += (double)pq;
       }
@@ -2005,6 +2013,7 @@ struct ApplyParams {
   unsigned char* mask_out;
   unsigned long long seed;
   unsigned drop_thresh;
+  bool y_tmajor;            // order of yraw's vectors inside a block of 64 lane-units (see yvec): set in the float16 training modes
 };
 
 // Philox-2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter-based, so every element's draw is a
@@ -2041,7 +2050,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
   const int j = lane & 15, g = lane >> 4, ch = n * 16 + j;
   const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
   float v[NV];
-  load_unit<NV>(p.yraw, p.y_scale, band, (size_t)u, v);
+  load_unit<NV>(p.yraw, p.y_scale, band, (size_t)u, v, p.y_tmajor);
   if constexpr (LAYER == 2) {   // slots that are no positions of the plane: keep them 0 for the backward pass (it reads every slot)
     bool touched = false;
 #pragma unroll
@@ -2058,9 +2067,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
           h16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = (_Float16)(v[4 * t + r] * p.y_scale[band * 2]);   // exact: v came from h / s
-          reinterpret_cast<h16x4*>(p.yraw)[(size_t)u * C::MT + t] = h;
+          reinterpret_cast<h16x4*>(p.yraw)[yvec((size_t)u, t, C::MT, p.y_tmajor)] = h;
         } else {
-          reinterpret_cast<f32x4*>(p.yraw)[(size_t)u * C::MT + t] = f32x4{v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+          reinterpret_cast<f32x4*>(p.yraw)[yvec((size_t)u, t, C::MT, p.y_tmajor)] = f32x4{v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
         }
       }
     }
@@ -2145,6 +2154,7 @@ struct ApplyBwdParams {
   double count;
   int chunks;              // pass A: blocks per (clip, band)
   const long long* clips;  // cross-rank statistics: see FoldParams::clips (count = clips[0] * rows * cols)
+  bool y_tmajor;           // see ApplyParams::y_tmajor
 };
 __device__ __forceinline__ double bwd_count(const ApplyBwdParams& p) {
   return p.clips ? (double)p.clips[0] * (double)p.rows * (double)p.cols : p.count;
@@ -2241,7 +2251,7 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
     const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
     const size_t u = ((((size_t)clip * p.nsub + band) * p.tiles_r + tr) * p.tiles_c + tc) * NT + n;
     float v[NV], df[NV];
-    load_unit<NV>(p.yraw, p.y_scale, band, u * 64 + lane, v);
+    load_unit<NV>(p.yraw, p.y_scale, band, u * 64 + lane, v, p.y_tmajor);
     unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
@@ -2363,7 +2373,7 @@ struct WgradParams {
 // NW waves per workgroup (4: two independent workgroups per CU, so that one's loads / barrier overlap the other's MFMAs)
 // SUB: pool height of the layer (tile = SUB rows x 40 / 80 columns, patch 8 x (SUB + 6) x 46 / 86)
 template <int SUB, int NW>
-__global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(NW * 64, SUB == 2 ? 4 : 2) void conv1_wgrad_kernel(const WgradParams p) {   // SUB 2: two workgroups per CU
   using C = CC<1, SUB>;
   constexpr int PR = C::PR, PC = C::PC, CHS = PR * PC, PATCH = 8 * CHS;
   constexpr int NCV = (PC + 63) / 64;  // 64-lane loads per patch row
@@ -2524,31 +2534,36 @@ __global__ __launch_bounds__(NW * 64) void conv1_wgrad_kernel(const WgradParams 
     __builtin_amdgcn_sched_barrier(0);
     const float* pb = patch[buf];
     const float* dyl = dybuf[buf];
-    f32x4 ac[2][5];   // A operands from the shared copy
+    // A operands from the shared copy, four k-steps (one 16-byte read per M-tile) at a time into a double buffer, one group ahead of
+    // their MFMAs (pitch 5 units per lane: conflict-free).  Holding the whole tile's 2 x 5 vectors cost 24 more registers and kept
+    // the kernel at one workgroup per CU -- two waves per SIMD in lockstep, nobody to cover a barrier or an LDS round trip.
+    f32x4 ag[2][2];
+    auto read_a = [&](int grp) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int t5 = 0; t5 < 5; ++t5) ac[c][t5] = reinterpret_cast<const f32x4*>(dybuf[buf])[(c * 64 + lane) * 5 + t5];
-    // B operands: one float per k-step, read from LDS into a ring of 8 FIVE k-steps (320 matrix cycles) ahead, one read behind
+      for (int c = 0; c < 2; ++c) ag[grp & 1][c] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 5 + grp % 5];
+    };
+    read_a(0);
+    // B operands: one float per k-step, read from LDS into a ring of 4 THREE k-steps ahead, one read behind
     // the first MFMA of every step (pinned by sched_barrier).  Before, a block of 20 reads stood in front of every N-tile, and the
     // two waves of a SIMD -- in lockstep, one barrier per tile -- issued theirs together while the matrix pipe idled.
-    constexpr int NS = KF * 20, LA = 5;
-    float bq[8];
+    constexpr int NS = KF * 20, LA = 3;
+    float bq[4];
     auto read_b = [&](int s2) __attribute__((always_inline)) {
       const int k2 = s2 / 20, e2 = s2 % 20, wv = e2 / C::WIN, pos = e2 % C::WIN;
-      bq[s2 & 7] = pb[nbase[k2] + (pos / 5) * PC + 5 * wv + pos % 5];
+      bq[s2 & 3] = pb[nbase[k2] + (pos / 5) * PC + 5 * wv + pos % 5];
     };
 #pragma unroll
     for (int s2 = 0; s2 < LA; ++s2) read_b(s2);
     int piece = 0;
 #pragma unroll
     for (int s1 = 0; s1 < NS; ++s1) {   // the wave's own full N-tiles, flat step s1 = 20 k + e
-      const int k = s1 / 20, e = s1 % 20;
-      const float b = bq[s1 & 7];
-      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[0][e >> 2][e & 3], b, acc[0][k], 0, 0, 0);
+      const int k = s1 / 20, e = s1 % 20, grp = s1 / 4;
+      const float b = bq[s1 & 3];
+      acc[0][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[grp & 1][0][e & 3], b, acc[0][k], 0, 0, 0);
       if (s1 + LA < NS) read_b(s1 + LA);
+      if ((s1 & 3) == 0 && s1 + 4 < NS) read_a(grp + 1);
       __builtin_amdgcn_sched_barrier(0);
-      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[1][e >> 2][e & 3], b, acc[1][k], 0, 0, 0);
+      acc[1][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[grp & 1][1][e & 3], b, acc[1][k], 0, 0, 0);
       // one prefetch instruction per 10 MFMAs (12 slots), or per 5 when the tile needs more than 12 pieces
       if ((RPW + NDY > 12 ? ((e % 5) == 1 || (e % 5) == 3) : (e % 5) == 2)) {
         prefetch_piece(piece, pfn, dqn, pmn);
@@ -2621,6 +2636,12 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   const int sh_nidx = (NTN - 1) * 16 + j;
   const int sh_base = (sh_nidx < 392 ? (sh_nidx / 49) * CHS + ((sh_nidx % 49) / 7) * PC + (sh_nidx % 49) % 7 : 0) + goff;
   const float sh_mask = sh_nidx < 392 ? 1.f : 0.f;
+  // LOW tiles (the last tile row when it holds at most 2 output rows: rows 8, 9 of 10 at the default geometry).  In the forward
+  // pass's accumulator order their 16 positions sit in slots 0..7 of the two upper lane groups and the two lower groups are
+  // padding, i.e. half of every MFMA's K.  Here the lower groups take the tile's SECOND row instead: lane group g works on
+  // (row g >> 1, columns 4 (g & 1) .. + 3) -- its A operand is slot 4 + e of the lane 32 below it, its B operand the patch
+  // one row down -- and the tile is done in 4 k-steps instead of 8 (conv2's weight gradient: 24 -> 20 k-steps per tile column).
+  const int glow = (g >> 1) * PC + 4 * (g & 1) - goff;   // added to nbase / sh_base in the low tiles
 
   struct Item {
     int band, chunk, clip, tr, tc;
@@ -2739,19 +2760,22 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
     // instructions per N-tile.  Before, the A reads sat directly in front of their MFMAs and a block of 16 B reads in front of
     // every N-tile: both waves of a SIMD (they run in lockstep, one barrier per tile) stalled on them together.
     const bool low = 8 * __builtin_amdgcn_readfirstlane(cur.tr) + 2 >= p.in_rows;   // second tile row: only output rows 8, 9 exist -> k-steps 0..7 (wave-uniform)
-    auto mma = [&](auto ne_c) __attribute__((always_inline)) {   // NE k-steps per N-tile: 16, or 8 in the low tiles
+    auto mma = [&](auto ne_c) __attribute__((always_inline)) {   // NE k-steps per N-tile: 16, or 4 in the low tiles (see glow)
       constexpr int NE = decltype(ne_c)::value, NS = KF * NE;   // flat step s = k * NE + e
+      constexpr bool LOW = NE == 4;
       constexpr int LA = 3;                                     // B look-ahead in k-steps
       f32x4 ag[2][4];
       float bq[4];
       auto read_b = [&](int s2) __attribute__((always_inline)) {
         const int k2 = s2 / NE, e2 = s2 % NE;
-        bq[s2 & 3] = pb[nbase[k2] + (e2 >> 2) * PC + (e2 & 3)];
+        bq[s2 & 3] = LOW ? pb[nbase[k2] + glow + e2] : pb[nbase[k2] + (e2 >> 2) * PC + (e2 & 3)];
       };
       auto read_a = [&](int grp) __attribute__((always_inline)) {   // group = 4 k-steps of one N-tile: the same dy values for every N-tile
         const int q = grp % (NE / 4);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ag[grp & 1][c] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * (DYP / 4) + q];
+        for (int c = 0; c < 4; ++c)
+          ag[grp & 1][c] = LOW ? reinterpret_cast<const f32x4*>(dyl)[(c * 64 + (lane & 31)) * (DYP / 4) + (lane >> 5)]
+                               : reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * (DYP / 4) + q];
       };
       read_a(0);
 #pragma unroll
@@ -2766,7 +2790,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
           acc[c][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag[grp & 1][c][e & 3], b, acc[c][k], 0, 0, 0);
           if (c == 0 && s1 + LA < NS) read_b(s1 + LA);
           if (c == 1 && (e & 3) == 0 && s1 + 4 < NS) read_a(grp + 1);
-          if (c == 2 && (e & 3) == 2 && e < 8) {   // two prefetch instructions per N-tile, in the k-steps every tile executes
+          if (c == 2 && (LOW ? (e & 1) == 0 : ((e & 3) == 2 && e < 8))) {   // two prefetch instructions per N-tile
             prefetch_piece(piece, pfn, dqn, pmn);
             ++piece;
           }
@@ -2774,18 +2798,18 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
         }
       }
     };
-    if (low) mma(std::integral_constant<int, 8>{});
+    if (low) mma(std::integral_constant<int, 4>{});
     else mma(std::integral_constant<int, 16>{});
-    {   // shared N-tile 24: two k-steps per wave (one in the low tiles)
-      const int e0 = low ? wave : 2 * wave, cnt = low ? 1 : 2;
+    {   // shared N-tile 24: two k-steps per wave (low tiles: 4 k-steps in all, one each for waves 0..3)
+      const int e0 = low ? wave : 2 * wave, cnt = low ? (wave < 4 ? 1 : 0) : 2;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         if (q < cnt) {
           const int e = e0 + q;
-          const float b = pb[sh_base + (e >> 2) * PC + (e & 3)] * sh_mask;
+          const float b = (low ? pb[sh_base + glow + e] : pb[sh_base + (e >> 2) * PC + (e & 3)]) * sh_mask;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float a = dyl[(c * 64 + lane) * DYP + e];
+            const float a = low ? dyl[(c * 64 + (lane & 31)) * DYP + 4 * (lane >> 5) + e] : dyl[(c * 64 + lane) * DYP + e];
             acc[c][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c][KF], 0, 0, 0);
           }
         }
@@ -3549,6 +3573,7 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
       if (e->train_f16 == 2) ap.out_l16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_l16);
       if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys1);
     }
+    ap.y_tmajor = train_fwd16(e);
     ap.pool_h = e->sub;   // 2 x 40 tiles with 16-mel sub-bands (f16 modes): MaxPool2d((1, 5))
     if (taps && taps->drop1_mask_out && taps->drop1_p > 0.f) {   // Dropout drawn in the kernel
       MST_REQUIRE(taps->drop1_p < 1.f, "mst_encoder_forward_train: drop1_p must be in [0, 1)");
@@ -3647,6 +3672,7 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
     ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64,
                    nullptr, nullptr, L.W1};
     if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys2);
+    ap.y_tmajor = train_fwd16(e);
     hipLaunchKernelGGL((apply_kernel<2, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -3737,6 +3763,7 @@ int mst_encoder_train_backward_apply_phase(const mst_encoder* e, int layer, int 
       p.dy = nullptr;
     }
   }
+  p.y_tmajor = train_bwd16(e);
   if (layer == 1) {
     p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
     p.dy_acc = dy ? nullptr : reinterpret_cast<float*>(ws + T.y1);
@@ -3877,7 +3904,8 @@ int mst_encoder_train_conv1_wgrad_in(const mst_encoder* e, const mst_logmel_in* 
                  (long long)8 * e->cfg.n_mels * frames, 0};
   const long long total = (long long)ns * B * T.tr1 * T.tc1;
   MST_REQUIRE(total < (1LL << 31), "mst_encoder_train_conv1_wgrad: too many tiles");
-  const int g8 = (int)std::min<long long>(e->num_cus, total);
+  // (20-mel sub-bands: the kernel fits two workgroups per CU -- 126 registers, 44 KB of LDS -- and is launched that wide)
+  const int g8 = (int)std::min<long long>((long long)e->num_cus * (e->sub == 2 ? 2 : 1), total);
   const float* unscale = nullptr;
   if (train_bwd16(e)) {   // f16 operands, K = positions x 8 clips (encoder_f16train.inc)
     unscale = reinterpret_cast<const float*>(ws + T.t_bscale);
