@@ -272,6 +272,14 @@ int mst_encoder_update_trunk_params(mst_encoder* enc, const float* conv1_w, cons
                                     const float* bn1_b, const float* conv2_w, const float* conv2_b,
                                     const float* bn2_w, const float* bn2_b, void* stream);
 
+/* Device-side refresh of EVERY parameter table of an existing encoder -- what a trainer calls before a validation pass after
+ * optimizer steps (src/train.py:388-427 follows :292-296): `w` has mst_encoder_create's fields, but every pointer is a DEVICE
+ * tensor in state_dict layout (the sub-band tensors stacked over the bands).  Fragment swizzles, the eval BatchNorm fold, the
+ * float16 fragments with their power-of-two pre-scales, transposes and copies all run as kernels on `stream`: no host
+ * round trip, no synchronisation, no allocation after the first call.  The configuration (shapes) must be the one the
+ * encoder was created with.                                                                                           */
+int mst_encoder_update_params(mst_encoder* enc, const mst_encoder_weights* device_weights, void* stream);
+
 /* Backward of max-pool / ReLU / FiLM / BatchNorm(batch statistics) of conv layer 1 or 2, from the activations that
  * mst_encoder_forward_train left in `workspace` (same buffer, same B and frames).
  * dpool: gradient of the pooled activation; element (clip, band, ch, r, c) at

@@ -103,6 +103,7 @@ SYMBOLS = {
     "mst_encoder_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_update_params": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.c_void_p]),
     "mst_encoder_train_layout_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "mst_encoder_forward_train_in": (C.c_int, [C.c_void_p, C.POINTER(LogmelIn), C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                                C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),

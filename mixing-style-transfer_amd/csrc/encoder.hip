@@ -1691,7 +1691,7 @@ struct AttnParams {
   const float* x;       // pool_in [B][C][W]
   const float* w1frag;  // [C/4][16][64]
   const float *b1, *w2;
-  float b2;
+  const float* b2;      // device [1]
   float* scores;        // [B][W]
   int B, C, W, A;
 };
@@ -1743,7 +1743,7 @@ __global__ __launch_bounds__(256) void attn_scores_kernel(const AttnParams p) {
   if (threadIdx.x < 16) {
     const int mr = mt * 16 + threadIdx.x;
     if (mr < M)
-      p.scores[mr] = ((part_s[0][threadIdx.x] + part_s[1][threadIdx.x]) + (part_s[2][threadIdx.x] + part_s[3][threadIdx.x])) + p.b2;
+      p.scores[mr] = ((part_s[0][threadIdx.x] + part_s[1][threadIdx.x]) + (part_s[2][threadIdx.x] + part_s[3][threadIdx.x])) + p.b2[0];
   }
 }
 
@@ -1870,8 +1870,9 @@ struct mst_encoder {
   float *s1 = nullptr, *t1 = nullptr, *s2 = nullptr, *t2 = nullptr;
   float *w0t = nullptr, *b0 = nullptr, *w3t = nullptr, *b3 = nullptr, *hwt = nullptr, *hb = nullptr;
   float *att0frag = nullptr, *att0_b = nullptr, *att2_w = nullptr, *projfrag = nullptr, *proj_b = nullptr;
-  float att2_b = 0.f;
+  float* att2_b = nullptr;    // device [1]
   int num_cus = 256;
+  float *f16_wsc1e = nullptr, *f16_wsc2e = nullptr, *w2norm_e = nullptr;   // scratch of the device-side refresh (mst_encoder_update_params)
   void* w1frag16 = nullptr;   // conv1 weights as f16 hi/lo MFMA B fragments (opt-in split-precision path)
   void* w1frag16e = nullptr;  // the same weights in conv1_f16e_kernel's k order (14 steps: one tap column x four tap rows)
   void* w2frag16 = nullptr;   // conv2 likewise: [band][4 chunks][13 steps][4 nt][hi/lo][lane][8]
@@ -2958,7 +2959,6 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
     for (int n = 0; n < A / 16; ++n)
       for (int lane = 0; lane < 64; ++lane)
         af[((size_t)s * (A / 16) + n) * 64 + lane] = w->att0_w[(size_t)(n * 16 + (lane & 15)) * C + 4 * s + (lane >> 4)];
-  e->att2_b = w->att2_b[0];
   // per-(band, output channel) power-of-two pre-scale of the f16 weight fragments, and its inverse for the epilogues
   std::vector<int> wex1((size_t)ns * 32), wex2((size_t)ns * 64);
   std::vector<float> winv1((size_t)ns * 32), winv2((size_t)ns * 64);
@@ -3039,7 +3039,7 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
   UP(w1frag, f1); UP(w2frag, f2); UP(s1, s1); UP(t1, t1); UP(s2, s2); UP(t2, t2);
   UP(w0t, w0t); UP(w3t, w3t); UP(hwt, hwt); UP(projfrag, pfrag); UP(att0frag, af);
   UPP(b0, w->mlp0_b, H); UPP(b3, w->mlp3_b, H); UPP(hb, w->head_b, ns * 192);
-  UPP(att0_b, w->att0_b, A); UPP(att2_w, w->att2_w, A); UPP(proj_b, w->proj_b, E);
+  UPP(att0_b, w->att0_b, A); UPP(att2_w, w->att2_w, A); UPP(proj_b, w->proj_b, E); UPP(att2_b, w->att2_b, 1);
   UPP(c1b, w->conv1_b, ns * 32); UPP(bn1w, w->bn1_w, ns * 32); UPP(bn1b, w->bn1_b, ns * 32);
   UPP(c2b, w->conv2_b, ns * 64); UPP(bn2w, w->bn2_w, ns * 64); UPP(bn2b, w->bn2_b, ns * 64);
   if (!rc) {   // input-gradient fragments of conv2, built on the device from a temporary copy of the weights
@@ -3068,7 +3068,7 @@ void mst_encoder_destroy(mst_encoder* e) {
   if (!e) return;
   float* ptrs[] = {e->w1frag, e->w2frag, e->s1, e->t1, e->s2, e->t2, e->w0t, e->b0, e->w3t, e->b3, e->hwt,
                    e->hb, e->att0frag, e->att0_b, e->att2_w, e->projfrag, e->proj_b, e->c1b, e->bn1w, e->bn1b, e->c2b,
-                   e->bn2w, e->bn2b, e->w2dfrag};
+                   e->bn2w, e->bn2b, e->w2dfrag, e->att2_b, e->f16_wsc1e, e->f16_wsc2e, e->w2norm_e};
   for (float* q : ptrs) (void)hipFree(q);
   (void)hipFree(e->w1frag16), (void)hipFree(e->w1frag16e);
   (void)hipFree(e->w1norm), (void)hipFree(e->f16_winv1), (void)hipFree(e->f16_winv2);
@@ -3868,6 +3868,97 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
   const struct { float* dst; const float* src; int n; } cp[] = {
       {e->c1b, conv1_b, ns * 32}, {e->bn1w, bn1_w, ns * 32}, {e->bn1b, bn1_b, ns * 32},
       {e->c2b, conv2_b, ns * 64}, {e->bn2w, bn2_w, ns * 64}, {e->bn2b, bn2_b, ns * 64}};
+  for (const auto& c : cp) MST_HIP_CHECK(hipMemcpyAsync(c.dst, c.src, (size_t)c.n * 4, hipMemcpyDeviceToDevice, st));
+  return MST_OK;
+}
+
+// ---- device-side refresh of EVERY table of the encoder (eval and training) from device tensors in state_dict layout
+// BatchNorm(eval) folded with the convolution bias: y = s * conv + t  (as mst_encoder_create does on the host, in double)
+__global__ void bn_fold_eval_kernel(const float* cb, const float* bw, const float* bb, const float* mean, const float* var, int n,
+                                    float eps, float* s, float* t) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double sc = (double)bw[i] / sqrt((double)var[i] + (double)eps);
+  s[i] = (float)sc;
+  t[i] = (float)(sc * ((double)cb[i] - (double)mean[i]) + (double)bb[i]);
+}
+// [rows][cols] -> [cols][rows]
+__global__ void transpose_kernel(const float* __restrict__ w, float* __restrict__ t, int rows, int cols) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * cols) return;
+  const int c = (int)(i / rows), r = (int)(i % rows);   // destination-major: coalesced stores
+  t[i] = w[(size_t)r * cols + c];
+}
+// Linear weight [N][K] -> fp32-MFMA B fragments [K/4][N/16][64]: lane (n, kq) of step s, tile nt holds w[16 nt + n][4 s + kq]
+__global__ void linear_fragments_kernel(const float* __restrict__ w, float* __restrict__ f, int N, int K) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)N * K) return;
+  const int lane = (int)(i & 63);
+  const long long r = i >> 6;
+  const int nt = (int)(r % (N / 16)), st = (int)(r / (N / 16));
+  f[i] = w[(size_t)(nt * 16 + (lane & 15)) * K + 4 * st + (lane >> 4)];
+}
+// conv1 weights as float16 hi / lo B fragments in conv1_f16e_kernel's k order: [band][14 steps][2 nt][hi/lo][lane][8 channels],
+// step = (tap column st >> 1, upper / lower tap rows st & 1), lane group kq -> tap row 4 (st & 1) + (0, 2, 1, 3)[kq]
+__global__ void f16e_fragments_kernel(const float* __restrict__ w, const float* __restrict__ scale, _Float16* f, int nsub) {
+  const long long total = (long long)nsub * kF16StepsE * 2 * 64 * 8;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+  long long r = i >> 9;
+  const int n = (int)(r % 2);
+  r /= 2;
+  const int st = (int)(r % kF16StepsE), b = (int)(r / kF16StepsE);
+  const int kq = lane >> 4, tr = 4 * (st & 1) + (((kq & 1) << 1) | (kq >> 1)), tc = st >> 1, co = n * 16 + (lane & 15);
+  const float v = tr < 7 ? w[(((size_t)b * 32 + co) * 8 + j) * 49 + tr * 7 + tc] * scale[b * 32 + co] : 0.f;
+  const _Float16 h = (_Float16)v;
+  const size_t base = ((((size_t)b * kF16StepsE + st) * 2 + n) * 2) * 512;
+  f[base + (size_t)lane * 8 + j] = h;
+  f[base + 512 + (size_t)lane * 8 + j] = (_Float16)(v - (float)h);
+}
+
+int mst_encoder_update_params(mst_encoder* e, const mst_encoder_weights* w, void* stream) {
+  MST_REQUIRE(e && w, "mst_encoder_update_params: NULL argument");
+  for (const float* const* q = &w->conv1_w; q <= &w->proj_b; ++q)
+    MST_REQUIRE(*q != nullptr, "mst_encoder_update_params: NULL weight pointer");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int ns = e->cfg.n_subbands, H = e->cfg.film_hidden, Fd = e->cfg.feature_dim, A = e->cfg.attn_hidden, E = e->cfg.embed_dim, C = e->C;
+  // trunk: fp32 fragments, un-folded parameters, (training f16 modes) their float16 fragments
+  int rc = mst_encoder_update_trunk_params(e, w->conv1_w, w->conv1_b, w->bn1_w, w->bn1_b, w->conv2_w, w->conv2_b, w->bn2_w, w->bn2_b, stream);
+  if (rc) return rc;
+  auto blocks = [](long long n) { return dim3((unsigned)((n + 255) / 256)); };
+  // eval-mode BatchNorm affines
+  hipLaunchKernelGGL(bn_fold_eval_kernel, blocks(ns * 32), dim3(256), 0, st, w->conv1_b, w->bn1_w, w->bn1_b, w->bn1_mean, w->bn1_var,
+                     ns * 32, e->cfg.bn_eps, e->s1, e->t1);
+  hipLaunchKernelGGL(bn_fold_eval_kernel, blocks(ns * 64), dim3(256), 0, st, w->conv2_b, w->bn2_w, w->bn2_b, w->bn2_mean, w->bn2_var,
+                     ns * 64, e->cfg.bn_eps, e->s2, e->t2);
+  // eval-path float16 fragments (all three orders) with their per-channel power-of-two pre-scales and the filters' L1 norms
+  if (!e->f16_wsc1e) {
+    bool ok = hipMalloc(&e->f16_wsc1e, (size_t)ns * 32 * 4) == hipSuccess && hipMalloc(&e->f16_wsc2e, (size_t)ns * 64 * 4) == hipSuccess &&
+              hipMalloc(&e->w2norm_e, (size_t)ns * 64 * 4) == hipSuccess;
+    if (!ok) return mst::fail(MST_ENOMEM, "mst_encoder_update_params: out of device memory");
+  }
+  hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 32), dim3(64), 0, st, w->conv1_w, 32, (long long)32 * 392, 392, 1, 0, 392,
+                     e->f16_wsc1e, e->f16_winv1, e->w1norm);
+  hipLaunchKernelGGL(f16_wstats_kernel, dim3(ns * 64), dim3(64), 0, st, w->conv2_w, 64, (long long)64 * 1568, 1568, 1, 0, 1568,
+                     e->f16_wsc2e, e->f16_winv2, e->w2norm_e);
+  const long long n1 = (long long)ns * 1 * kF16Steps * 2 * 512, n2 = (long long)ns * 4 * kF16Steps * 4 * 512,
+                  n1e = (long long)ns * kF16StepsE * 2 * 512;
+  hipLaunchKernelGGL(f16_fragments_kernel, blocks(n1), dim3(256), 0, st, w->conv1_w, e->f16_wsc1e, reinterpret_cast<_Float16*>(e->w1frag16),
+                     ns, 32, 8, 2, 0);
+  hipLaunchKernelGGL(f16_fragments_kernel, blocks(n2), dim3(256), 0, st, w->conv2_w, e->f16_wsc2e, reinterpret_cast<_Float16*>(e->w2frag16),
+                     ns, 64, 32, 2, 0);
+  hipLaunchKernelGGL(f16e_fragments_kernel, blocks(n1e), dim3(256), 0, st, w->conv1_w, e->f16_wsc1e, reinterpret_cast<_Float16*>(e->w1frag16e), ns);
+  // FiLM MLP (transposed weights), attention pooling head (fp32-MFMA B fragments), biases
+  hipLaunchKernelGGL(transpose_kernel, blocks((long long)H * Fd), dim3(256), 0, st, w->mlp0_w, e->w0t, H, Fd);
+  hipLaunchKernelGGL(transpose_kernel, blocks((long long)H * H), dim3(256), 0, st, w->mlp3_w, e->w3t, H, H);
+  hipLaunchKernelGGL(transpose_kernel, blocks((long long)ns * 192 * H), dim3(256), 0, st, w->head_w, e->hwt, ns * 192, H);
+  hipLaunchKernelGGL(linear_fragments_kernel, blocks((long long)E * C), dim3(256), 0, st, w->proj_w, e->projfrag, E, C);
+  hipLaunchKernelGGL(linear_fragments_kernel, blocks((long long)A * C), dim3(256), 0, st, w->att0_w, e->att0frag, A, C);
+  MST_HIP_CHECK(hipGetLastError());
+  const struct { float* dst; const float* src; int n; } cp[] = {
+      {e->b0, w->mlp0_b, H}, {e->b3, w->mlp3_b, H}, {e->hb, w->head_b, ns * 192}, {e->att0_b, w->att0_b, A},
+      {e->att2_w, w->att2_w, A}, {e->att2_b, w->att2_b, 1}, {e->proj_b, w->proj_b, E}};
   for (const auto& c : cp) MST_HIP_CHECK(hipMemcpyAsync(c.dst, c.src, (size_t)c.n * 4, hipMemcpyDeviceToDevice, st));
   return MST_OK;
 }

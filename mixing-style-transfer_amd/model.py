@@ -226,6 +226,38 @@ class HipEncoder:
             except Exception:
                 pass
 
+    def update_from(self, model: "MixingStyleEncoder"):
+        """Refresh every table of this encoder from the module's CURRENT parameters and buffers ON THE DEVICE
+        (`mst_encoder_update_params`): what `hip_encoder()` does before a validation pass that follows optimizer steps
+        (src/train.py:388-427 after :292-296) -- no parameter crosses to the host, nothing synchronises.  The module must live
+        on a GPU and have the shapes this encoder was created with."""
+        ae, fe = model.audio_encoder, model.film_encoder
+        dev = fe.film_head.weight.device
+        if dev.type != "cuda":
+            raise _lib.MstError("HipEncoder.update_from needs the module on a GPU")
+        f32 = lambda t: t.detach().float().contiguous()
+        cat = lambda name: f32(torch.stack([getattr(getattr(c, name.split(".")[0]), name.split(".")[1]).detach()
+                                            for c in ae.subnet_cnns], 0))
+        keep = dict(
+            conv1_w=cat("conv1.weight"), conv1_b=cat("conv1.bias"), bn1_w=cat("bn1.weight"), bn1_b=cat("bn1.bias"),
+            bn1_mean=cat("bn1.running_mean"), bn1_var=cat("bn1.running_var"),
+            conv2_w=cat("conv2.weight"), conv2_b=cat("conv2.bias"), bn2_w=cat("bn2.weight"), bn2_b=cat("bn2.bias"),
+            bn2_mean=cat("bn2.running_mean"), bn2_var=cat("bn2.running_var"),
+            mlp0_w=f32(fe.feature_mlp[0].weight), mlp0_b=f32(fe.feature_mlp[0].bias),
+            mlp3_w=f32(fe.feature_mlp[3].weight), mlp3_b=f32(fe.feature_mlp[3].bias),
+            head_w=f32(fe.film_head.weight), head_b=f32(fe.film_head.bias),
+            att0_w=f32(ae.attention_pooling.attention[0].weight), att0_b=f32(ae.attention_pooling.attention[0].bias),
+            att2_w=f32(ae.attention_pooling.attention[2].weight), att2_b=f32(ae.attention_pooling.attention[2].bias),
+            proj_w=f32(ae.attention_pooling.projection[0].weight), proj_b=f32(ae.attention_pooling.projection[0].bias))
+        expect = (self.n_sub, 32, 8, 7, 7)
+        if tuple(keep["conv1_w"].shape) != expect or keep["proj_w"].shape[0] != self.embed_dim:
+            raise _lib.MstError(f"HipEncoder.update_from: parameter shapes {tuple(keep['conv1_w'].shape)} differ from the encoder's {expect}")
+        w = _lib.EncoderWeights(**{k: v.data_ptr() for k, v in keep.items()})
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mst_encoder_update_params(self._h, C.byref(w), _lib.stream_ptr(dev)), "mst_encoder_update_params")
+        # (the stacked temporaries are released to the caching allocator here; the kernels that read them are already queued on
+        # this stream, and the allocator re-issues a block only to work queued later on the same stream)
+
     def _ws_view(self, offset, nbytes, dtype):
         return self._ws_train[offset:offset + nbytes].view(dtype)
 
@@ -645,8 +677,14 @@ class MixingStyleEncoder(nn.Module):
 
     def hip_encoder(self) -> HipEncoder:
         v = self._params_version() + (self.conv1_precision,)
-        if self._hip is None or v != self._hip_version:  # weights changed (optimizer step / load_state_dict)
+        if self._hip is not None and v != self._hip_version and self._hip_version[-1] == self.conv1_precision and \
+                self.film_encoder.film_head.weight.is_cuda and getattr(self._hip, "_dev", None) == self.film_encoder.film_head.weight.device:
+            # weights changed (optimizer steps, load_state_dict): refresh the existing handle's tables on the device
+            self._hip.update_from(self)
+            self._hip_version = v
+        elif self._hip is None or v != self._hip_version:   # first use / another precision mode / another device: build (host-side tables)
             self._hip, self._hip_version = HipEncoder(self, self.conv1_precision), v
+            self._hip._dev = self.film_encoder.film_head.weight.device
         return self._hip
 
     def _needs_autograd(self, mixing_features):

@@ -279,3 +279,43 @@ def test_conv2_weight_gradient_from_the_float16_pool1_planes(precision):
     enc._ws_train = None
     with pytest.raises(Exception, match="float16"):
         enc.forward_train(lm, film=film, head=False, want_pool1=False)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3-all", "f16"])
+def test_eval_encoder_is_refreshed_on_the_device_after_parameter_updates(precision):
+    """src/train.py:388-427 (validate_epoch) follows :292-296 (optimizer steps): the eval encoder must see the new parameters.
+    `hip_encoder()` keeps its handle and rebuilds every table ON THE DEVICE (`mst_encoder_update_params`: MFMA fragment swizzles,
+    eval BatchNorm fold, float16 fragments + pre-scales, transposes) -- no parameter crosses to the host (checked with torch's
+    sync debug mode) -- and the result equals an encoder built from scratch from the same state_dict."""
+    cfg = cases.CFG_DEFAULT
+    m = _build(cfg, precision)
+    d = _stems(2, 44100, seed=9)
+    feats = torch.randn(2, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        e_before = m(d, feats)
+        first = m._hip
+        g = torch.Generator(device="cuda").manual_seed(5)
+        for p in m.parameters():                                  # "optimizer steps"
+            p.add_(torch.randn(p.shape, generator=g, device="cuda") * (0.02 * p.abs().mean()))
+        for name, b in m.named_buffers():                         # running statistics move too
+            if "running_mean" in name:
+                b.add_(0.05)
+            elif "running_var" in name:
+                b.mul_(1.1)
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            enc = m.hip_encoder()                                 # the refresh: device-side only
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        assert enc is first, "the handle is kept, its tables are rebuilt"
+        e_after = m(d, feats)
+        fresh = _build(cfg, precision)                            # another module, its encoder built from scratch through the host path
+        fresh.load_state_dict(m.state_dict())
+        e_fresh = fresh(d, feats)
+    assert fresh._hip is not first
+    assert (e_after - e_before).abs().max() > 1e-4, "the parameters did change"
+    if precision == "fp32":
+        assert torch.equal(e_after, e_fresh)
+    else:   # the L1 norms behind the range scales are summed in another order on the device: at most a last-bit difference
+        assert (e_after - e_fresh).abs().max().item() <= 2e-6 * e_fresh.abs().max().item()
