@@ -288,7 +288,8 @@ int mst_encoder_update_params(mst_encoder* enc, const mst_encoder_weights* devic
  *        operand of a library convolution weight / input gradient); layer 1 only: NULL = keep it in the workspace in
  *        accumulator order for mst_encoder_train_conv1_wgrad.
  * dfilm: [B][n_sub*192], the layer's gamma / beta slots are ACCUMULATED (+=): zero it once per step.
- * dbn:   out [n_sub][C][2] = (d BatchNorm weight, d BatchNorm bias).                                              */
+ * dbn:   out [2][n_sub][C]: the plane of d BatchNorm weight, then the plane of d BatchNorm bias (each is the stacked
+ *        gradient tensor of its parameter family).                                                               */
 int mst_encoder_train_backward_apply(const mst_encoder* enc, int layer, int B, int frames, const float* dpool,
                                      long long dp_clip, long long dp_band, long long dp_ch, float* dy, float* dfilm,
                                      float* dbn, void* workspace, size_t workspace_bytes, void* stream);

@@ -2832,7 +2832,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
 __global__ void sums_to_dbn_kernel(const mst::DetAcc* sums, float* dbn, int n, const float* unscale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const double u = unscale ? (double)unscale[1] : 1.0;
-  if (i < n) dbn[2 * i] = (float)(mst::det_get(sums[2 * i + 1]) * u), dbn[2 * i + 1] = (float)(mst::det_get(sums[2 * i]) * u);
+  if (i < n) dbn[i] = (float)(mst::det_get(sums[2 * i + 1]) * u), dbn[n + i] = (float)(mst::det_get(sums[2 * i]) * u);   // planes: d weight | d bias
 }
 
 // dfilm[clip][band][goff + ch] += gamma gradient, [boff + ch] += beta gradient of this layer (single writer per element)
@@ -3795,7 +3795,7 @@ int mst_encoder_train_backward_apply_phase(const mst_encoder* e, int layer, int 
     else if (layer == 1) hipLaunchKernelGGL((apply_bwd_reduce_kernel<1, 1>), gr, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((apply_bwd_reduce_kernel<2, 2>), gr, dim3(256), 0, st, p);
     MST_HIP_CHECK(hipGetLastError());
-    // dbn[band][ch] = (dgamma_bn, dbeta_bn) = (S2, S1) as fp32
+    // dbn = two planes [band][ch]: dgamma_bn = S2, then dbeta_bn = S1, as fp32
     hipLaunchKernelGGL(sums_to_dbn_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st, sums, dbn, ns * cout, unscale);
     hipLaunchKernelGGL(dfilm_finish_kernel, dim3((B * ns * 2 * cout + 255) / 256), dim3(256), 0, st, p.dfilm_acc, dfilm,
                        B * ns * 192, p.goff, p.boff, cout, unscale);

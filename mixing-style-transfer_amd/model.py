@@ -445,7 +445,7 @@ class HipEncoder:
             assert dpool.dim() == 5 and dpool.stride(4) == 1 and dpool.stride(3) == W1
             st = (dpool.stride(0), dpool.stride(1), dpool.stride(2))
             dy = None if inplace else torch.empty(self.n_sub, B, 32, self.split, frames, device=dev)
-            dbn = torch.empty(self.n_sub, 32, 2, device=dev)
+            dbn = torch.empty(2, self.n_sub, 32, device=dev)   # planes: d weight | d bias
         else:
             dpool = dpool.contiguous()
             W2 = W1 // 4
@@ -455,7 +455,7 @@ class HipEncoder:
                                  dtype=torch.float16)
             else:
                 dy = torch.empty(self.n_sub, B, 64, self.split // self.sub, W1, device=dev)
-            dbn = torch.empty(self.n_sub, 64, 2, device=dev)
+            dbn = torch.empty(2, self.n_sub, 64, device=dev)
         need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
         for phase in ((0,) if world == 0 else (1, 2, 3)):
             with torch.cuda.device(dev):
@@ -468,7 +468,7 @@ class HipEncoder:
                 yield "max", self.scale_view(B, frames)
             elif phase == 2:
                 yield "sum", self.stats_view(layer, B, frames)
-        return dy, dbn
+        return dy, dbn.permute(1, 2, 0)   # (n_sub, C, 2) view: [..., 0] / [..., 1] are the contiguous stacked gradients
 
     def preferred_layout(self):
         """The log-mel layout this encoder's eval forward reads fastest (_lib.LOGMEL_*): the channel-minor form of its conv1
@@ -620,7 +620,7 @@ class _HipTrunk(torch.autograd.Function):
         gw2 = enc.conv2_wgrad(p1, B, Fr)          # weight gradient on dy2 in accumulator order
         gb2 = torch.zeros(ns, 64, device=dev)   # exactly 0 in front of a batch-statistics BatchNorm
         mark("conv2_wgrad")
-        dbn2w, dbn2b = dbn2[..., 0].contiguous(), dbn2[..., 1].contiguous()
+        dbn2w, dbn2b = dbn2[..., 0], dbn2[..., 1]   # contiguous planes (no copies)
         reducer = ctx.reducer
         if reducer is not None:   # data parallel: the conv2-side gradients are final -- their all-reduce runs behind the rest of
             reducer.reduce_stacked("conv2", [gw2, gb2, dbn2w, dbn2b])   # this backward (dist.GradientReducer)
@@ -634,7 +634,7 @@ class _HipTrunk(torch.autograd.Function):
         if _TRAIN_TIMING:
             torch.cuda.synchronize()
             _HipTrunk.last_timing = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
-        dbn1w, dbn1b = dbn1[..., 0].contiguous(), dbn1[..., 1].contiguous()
+        dbn1w, dbn1b = dbn1[..., 0], dbn1[..., 1]
         if reducer is not None:
             reducer.reduce_stacked("conv1", [gw1, gb1, dbn1w, dbn1b])
         fams = (gw1, gb1, dbn1w, dbn1b, gw2, gb2, dbn2w, dbn2b)
@@ -720,6 +720,29 @@ class MixingStyleEncoder(nn.Module):
             self._trunk_flat_bufs = flat
         return flat, params
 
+    def _bn_flat(self, name):
+        """BatchNorm running statistics of layer `name` ("bn1" / "bn2") as views of 3 STACKED tensors (running_mean, running_var
+        (n_sub, C) and num_batches_tracked (n_sub,)), so that the per-step update is five small launches per layer instead of one
+        per sub-band and buffer.  Buffer objects, names, shapes and state_dict are unchanged (see _trunk_flat)."""
+        bns = [getattr(c, name) for c in self.audio_encoder.subnet_cnns]
+        cache = self.__dict__.setdefault("_bn_flat_bufs", {})
+        flat = cache.get(name)
+        ns = len(bns)
+        keys = ("running_mean", "running_var", "num_batches_tracked")
+        ok = flat is not None and all(
+            b.shape[0] == ns and getattr(bns[0], k).data_ptr() == b.data_ptr() and getattr(bns[-1], k).data_ptr() == b[ns - 1].data_ptr()
+            and getattr(bns[0], k).dtype == b.dtype for k, b in zip(keys, flat))
+        if not ok:
+            flat = []
+            with torch.no_grad():
+                for k in keys:
+                    buf = torch.stack([getattr(bn, k).detach() for bn in bns])
+                    for i, bn in enumerate(bns):
+                        getattr(bn, k).data = buf[i]
+                    flat.append(buf)
+            cache[name] = flat
+        return flat
+
     def _forward_train_hip(self, logmel, mixing_features):
         """Training forward with the trunk in libmst.so (see _HipTrunk); FiLM MLP and attention head stay torch modules."""
         ae, fe = self.audio_encoder, self.film_encoder
@@ -748,12 +771,12 @@ class MixingStyleEncoder(nn.Module):
                 mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * corr
                 bns = [getattr(c, name) for c in cn]
                 moms = {bn.momentum if bn.momentum is not None else 0.1 for bn in bns}
-                if len(moms) == 1:   # one multi-tensor launch per update instead of 3 x n_sub tiny kernels
+                if len(moms) == 1:   # the buffers are views of stacked tensors: five launches per layer instead of 3 x n_sub
                     m = moms.pop()
-                    for bufs, new in (([bn.running_mean for bn in bns], mean), ([bn.running_var for bn in bns], var)):
-                        torch._foreach_mul_(bufs, 1 - m)
-                        torch._foreach_add_(bufs, list(new.unbind(0)), alpha=m)
-                    torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+                    rm, rv, nb = self._bn_flat(name)
+                    rm.mul_(1 - m).add_(mean, alpha=m)
+                    rv.mul_(1 - m).add_(var, alpha=m)
+                    nb.add_(1)
                 else:
                     for i, bn in enumerate(bns):
                         m = bn.momentum if bn.momentum is not None else 0.1
