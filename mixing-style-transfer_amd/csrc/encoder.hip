@@ -203,22 +203,22 @@ struct ConvParams {
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // one lane-unit (NV accumulator slots) of the raw convolution output: fp32, or (y_scale != NULL) float16 times the band's scale
-// Two orders of a unit's NV / 4 four-slot vectors inside its block of 64 lane-units (one (tile, N-tile)):
-//   lane-major (fp32 training mode): vector t of lane l at [64-block][l][t] -- the order the fp32 weight-gradient kernels stage;
-//   t-major    (float16 training modes, `tmajor`): [64-block][t][l] -- a wave's access to vector t is one contiguous run (512 B of
-//   float16, 1 KB of fp32) instead of 64 pieces 40 / 80 bytes apart, for the convolution's stores and for the three
-//   element-wise passes that read the tensor back.
-__device__ __forceinline__ size_t yvec(size_t unit, int t, int nvec, bool tmajor) {
-  return tmajor ? (unit & ~(size_t)63) * nvec + (size_t)t * 64 + (unit & 63) : unit * nvec + t;
+// Order of a lane-unit's NV / 4 four-slot vectors in the raw-output tensors ("accumulator order"): T-MAJOR inside every block of
+// 64 lane-units (one (tile, N-tile)): vector t of lane l at [64-block][t][l].  A wave's access to vector t is then one
+// contiguous run (512 B of float16, 1 KB of fp32) -- for the convolution's stores, for the element-wise passes that read the
+// tensor back and write the gradient over it, and for the weight-gradient kernels that stage it (lane-major, the first
+// version, made every such access 64 pieces 40 / 80 bytes apart: five times the cache lines per instruction).
+__device__ __forceinline__ size_t yvec(size_t unit, int t, int nvec) {
+  return (unit & ~(size_t)63) * nvec + (size_t)t * 64 + (unit & 63);
 }
 template <int NV>
-__device__ __forceinline__ void load_unit(const void* yraw, const float* y_scale, int band, size_t unit, float (&v)[NV], bool tmajor) {
+__device__ __forceinline__ void load_unit(const void* yraw, const float* y_scale, int band, size_t unit, float (&v)[NV]) {
   if (y_scale) {   // kernel-uniform
     const float inv = y_scale[band * 2 + 1];
     const h16x4* s = reinterpret_cast<const h16x4*>(yraw);
 #pragma unroll
     for (int t = 0; t < NV / 4; ++t) {
-      const h16x4 q = s[yvec(unit, t, NV / 4, tmajor)];
+      const h16x4 q = s[yvec(unit, t, NV / 4)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * t + r] = (float)q[r] * inv;
     }
@@ -226,7 +226,7 @@ __device__ __forceinline__ void load_unit(const void* yraw, const float* y_scale
     const f32x4* s = reinterpret_cast<const f32x4*>(yraw);
 #pragma unroll
     for (int t = 0; t < NV / 4; ++t) {
-      const f32x4 q = s[yvec(unit, t, NV / 4, tmajor)];
+      const f32x4 q = s[yvec(unit, t, NV / 4)];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
     }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const float b = p.bias[cur.band * C::COUT + n * 16 + j];
-        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+        f32x4* dst = reinterpret_cast<f32x4*>(yb) + (size_t)n * (64 * MT) + lane;   // t-major (yvec): vector t at dst[64 t]
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
             }
             if (row < p.raw_rows && col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
-          dst[t] = v;
+          dst[64 * t] = v;
         }
       }
     }
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
             st[n][0] += (double)v, st[n][1] += (double)v * (double)v;
             const int tr8 = row >> 3, rr = row & 7, tc8 = col >> 3, cc8 = col & 7;
             const int lane8 = 16 * (((rr >> 2) << 1) | (cc8 >> 2)) + j, e8 = 4 * (rr & 3) + (cc8 & 3);
-            yplane[((((size_t)tr8 * p.acc_tc + tc8) * NT + n) * 64 + lane8) * 16 + e8] = v;
+            yplane[(((((size_t)tr8 * p.acc_tc + tc8) * NT + n) * 4 + (e8 >> 2)) * 64 + lane8) * 4 + (e8 & 3)] = v;   // t-major (yvec)
           }
         }
       }
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const float b = p.bias[cur.band * C::COUT + n * 16 + j];
-        f32x4* dst = reinterpret_cast<f32x4*>(yb + (size_t)(n * 64 + lane) * (4 * MT));
+        f32x4* dst = reinterpret_cast<f32x4*>(yb) + (size_t)n * (64 * MT) + lane;   // t-major (yvec): vector t at dst[64 t]
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           f32x4 v = acc[t][n];
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
             const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
             if (col < p.raw_cols) st[n][0] += (double)v[r], st[n][1] += (double)v[r] * (double)v[r];
           }
-          dst[t] = v;
+          dst[64 * t] = v;
         }
       }
     } else
@@ -1124,8 +1124,8 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
             const int col = C::TCOLS * cur.tc + 5 * (C::WPG * g + wv) + pos % 5;
             if (col < p.raw_cols) ps += v[r], pq = fmaf(v[r], v[r], pq);
           }
-          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[yvec(unit, t, MT, true)] = h;   // t-major: whole-line stores
-          else reinterpret_cast<f32x4*>(p.yraw)[yvec(unit, t, MT, true)] = v;
+          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[yvec(unit, t, MT)] = h;   // t-major: whole-line stores
+          else reinterpret_cast<f32x4*>(p.yraw)[yvec(unit, t, MT)] = v;
         }
         st[n][0] += (double)ps, st[n][1] += (double)pq;
       }
@@ -1653,8 +1653,8 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
             const int row = 8 * cur.tr + 4 * (g >> 1) + t, col = 8 * cur.tc + 4 * (g & 1) + r;
             if (row < p.raw_rows && col < p.raw_cols) ps += v[r], pq = fmaf(v[r], v[r], pq);
           }
-          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[yvec(unit, t, MT, true)] = h;   // t-major: whole-line stores
-          else reinterpret_cast<f32x4*>(p.yraw)[yvec(unit, t, MT, true)] = v;
+          if constexpr (MODE == 2) reinterpret_cast<h16x4*>(p.yraw16)[yvec(unit, t, MT)] = h;   // t-major: whole-line stores
+          else reinterpret_cast<f32x4*>(p.yraw)[yvec(unit, t, MT)] = v;
         }
         st[n][0] += (double)ps, st[n][1] += (double)pq;
       }
@@ -2014,7 +2014,6 @@ struct ApplyParams {
   unsigned char* mask_out;
   unsigned long long seed;
   unsigned drop_thresh;
-  bool y_tmajor;            // order of yraw's vectors inside a block of 64 lane-units (see yvec): set in the float16 training modes
 };
 
 // Philox-2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter-based, so every element's draw is a
@@ -2051,7 +2050,7 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
   const int j = lane & 15, g = lane >> 4, ch = n * 16 + j;
   const float2 ac = p.aff[((size_t)clip * p.nsub + band) * C::COUT + ch];
   float v[NV];
-  load_unit<NV>(p.yraw, p.y_scale, band, (size_t)u, v, p.y_tmajor);
+  load_unit<NV>(p.yraw, p.y_scale, band, (size_t)u, v);
   if constexpr (LAYER == 2) {   // slots that are no positions of the plane: keep them 0 for the backward pass (it reads every slot)
     bool touched = false;
 #pragma unroll
@@ -2068,9 +2067,9 @@ __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {
           h16x4 h;
 #pragma unroll
           for (int r = 0; r < 4; ++r) h[r] = (_Float16)(v[4 * t + r] * p.y_scale[band * 2]);   // exact: v came from h / s
-          reinterpret_cast<h16x4*>(p.yraw)[yvec((size_t)u, t, C::MT, p.y_tmajor)] = h;
+          reinterpret_cast<h16x4*>(p.yraw)[yvec((size_t)u, t, C::MT)] = h;
         } else {
-          reinterpret_cast<f32x4*>(p.yraw)[yvec((size_t)u, t, C::MT, p.y_tmajor)] = f32x4{v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
+          reinterpret_cast<f32x4*>(p.yraw)[yvec((size_t)u, t, C::MT)] = f32x4{v[4 * t], v[4 * t + 1], v[4 * t + 2], v[4 * t + 3]};
         }
       }
     }
@@ -2155,7 +2154,6 @@ struct ApplyBwdParams {
   double count;
   int chunks;              // pass A: blocks per (clip, band)
   const long long* clips;  // cross-rank statistics: see FoldParams::clips (count = clips[0] * rows * cols)
-  bool y_tmajor;           // see ApplyParams::y_tmajor
 };
 __device__ __forceinline__ double bwd_count(const ApplyBwdParams& p) {
   return p.clips ? (double)p.clips[0] * (double)p.rows * (double)p.cols : p.count;
@@ -2252,7 +2250,7 @@ __global__ __launch_bounds__(256) void apply_bwd_reduce_kernel(const ApplyBwdPar
     const float gf = p.film[((size_t)clip * p.nsub + band) * 192 + p.goff + ch];
     const size_t u = ((((size_t)clip * p.nsub + band) * p.tiles_r + tr) * p.tiles_c + tc) * NT + n;
     float v[NV], df[NV];
-    load_unit<NV>(p.yraw, p.y_scale, band, u * 64 + lane, v, p.y_tmajor);
+    load_unit<NV>(p.yraw, p.y_scale, band, u * 64 + lane, v);
     unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
 #pragma unroll
     for (int e = 0; e < NV; ++e) {
@@ -2300,18 +2298,18 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
   const double cnt = bwd_count(p);
   const double m1 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2]) / cnt,
                m2 = mst::det_get(p.sums[((size_t)band * C::COUT + ch) * 2 + 1]) / cnt;
-  const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw + (size_t)u * NV);
+  const f32x4* src = reinterpret_cast<const f32x4*>(p.yraw);
   float v[NV], df[NV];
 #pragma unroll
   for (int t = 0; t < C::MT; ++t) {
-    const f32x4 q = src[t];
+    const f32x4 q = src[yvec((size_t)u, t, C::MT)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[4 * t + r] = q[r];
   }
   unit_df<LAYER, SUB>(p, v, ac, clip, band, ch, tr, tc, g, df);
   const float k = gb * ms.y;
   if (p.dy_acc != nullptr) {   // in place, accumulator order (operand layout of the hand-written weight gradient); 0 outside
-    f32x4* dst = reinterpret_cast<f32x4*>(p.dy_acc + (size_t)u * NV);
+    f32x4* dst = reinterpret_cast<f32x4*>(p.dy_acc);
 #pragma unroll
     for (int t = 0; t < C::MT; ++t) {
       f32x4 q;
@@ -2323,7 +2321,7 @@ __global__ __launch_bounds__(256) void apply_bwd_dx_kernel(const ApplyBwdParams 
         const float zh = (v[e] - ms.x) * ms.y;
         q[r] = (row < p.rows && col < p.cols) ? k * (float)((double)gf * (double)df[e] - m1 - (double)zh * m2) : 0.f;
       }
-      dst[t] = q;
+      dst[yvec((size_t)u, t, C::MT)] = q;
     }
   }
   if (p.dy_h16 != nullptr) {
@@ -2541,7 +2539,7 @@ __global__ __launch_bounds__(NW * 64, SUB == 2 ? 4 : 2) void conv1_wgrad_kernel(
     f32x4 ag[2][2];
     auto read_a = [&](int grp) __attribute__((always_inline)) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) ag[grp & 1][c] = reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * 5 + grp % 5];
+      for (int c = 0; c < 2; ++c) ag[grp & 1][c] = reinterpret_cast<const f32x4*>(dyl)[(c * 5 + grp % 5) * 64 + lane];   // t-major copy
     };
     read_a(0);
     // B operands: one float per k-step, read from LDS into a ring of 4 THREE k-steps ahead, one read behind
@@ -2579,7 +2577,7 @@ __global__ __launch_bounds__(NW * 64, SUB == 2 ? 4 : 2) void conv1_wgrad_kernel(
           const int e = sh_e0 + q;
           const int wv = e / C::WIN, pos = e % C::WIN;
           const float b = pb[sh_base + (pos / 5) * PC + 5 * wv + pos % 5] * sh_mask;
-          const float a0 = dyl[(0 * 64 + lane) * 20 + e], a1 = dyl[(1 * 64 + lane) * 20 + e];
+          const float a0 = dyl[((0 * 5 + (e >> 2)) * 64 + lane) * 4 + (e & 3)], a1 = dyl[((1 * 5 + (e >> 2)) * 64 + lane) * 4 + (e & 3)];
           acc[0][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0][KF], 0, 0, 0);
           acc[1][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1][KF], 0, 0, 0);
         }
@@ -2609,11 +2607,9 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
   constexpr int NPF = 4;        // patch elements per thread: flat index f = tid + 512 i over [8*14 rows][16 pitch]
   constexpr int NDY = 2;        // float4 of dy per thread: 4 * 64 * 16 floats per tile
   __shared__ float patch[2][PATCH];
-  constexpr int DYP = 20;       // floats per (M-tile, lane) row of the LDS copy of dy: 16 values + 4 of padding -- 5 units of 16
-                                // bytes per lane, and lane * 5 mod 16 is a permutation inside every 16-lane group of a ds_read_b128:
-                                // the A-operand reads are conflict-free (at the natural pitch of 4 units they were 4-way conflicts,
-                                // SQ_LDS_BANK_CONFLICT 73 % of the LDS cycles, the LDS 57 % busy beside a 73 % busy matrix pipe)
-  __shared__ __attribute__((aligned(16))) float dybuf[2][4 * 64 * DYP];
+  // LDS copy of the tile's dy: a linear copy of the t-major tensor, [M-tile][vector q][lane] -- consecutive lanes read
+  // consecutive 16-byte units, conflict-free (the lane-major copy of the first version needed a padded pitch of 5 units)
+  __shared__ __attribute__((aligned(16))) float dybuf[2][4 * 64 * 16];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, g = lane >> 4;
@@ -2697,8 +2693,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
     }
 #pragma unroll
     for (int i = 0; i < NDY; ++i) {
-      const int idx = tid + i * kConvThreads;   // float4 number: (M-tile, lane) row idx >> 2, quarter idx & 3
-      reinterpret_cast<f32x4*>(dybuf[buf])[(idx >> 2) * (DYP / 4) + (idx & 3)] = dq[i];
+      reinterpret_cast<f32x4*>(dybuf[buf])[tid + i * kConvThreads] = dq[i];
     }
   };
 
@@ -2775,8 +2770,8 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
         const int q = grp % (NE / 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          ag[grp & 1][c] = LOW ? reinterpret_cast<const f32x4*>(dyl)[(c * 64 + (lane & 31)) * (DYP / 4) + (lane >> 5)]
-                               : reinterpret_cast<const f32x4*>(dyl)[(c * 64 + lane) * (DYP / 4) + q];
+          ag[grp & 1][c] = LOW ? reinterpret_cast<const f32x4*>(dyl)[(c * 4 + (lane >> 5)) * 64 + (lane & 31)]
+                               : reinterpret_cast<const f32x4*>(dyl)[(c * 4 + q) * 64 + lane];
       };
       read_a(0);
 #pragma unroll
@@ -2810,7 +2805,7 @@ __global__ __launch_bounds__(kConvThreads) void conv2_wgrad_kernel(const WgradPa
           const float b = (low ? pb[sh_base + glow + e] : pb[sh_base + (e >> 2) * PC + (e & 3)]) * sh_mask;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float a = low ? dyl[(c * 64 + (lane & 31)) * DYP + 4 * (lane >> 5) + e] : dyl[(c * 64 + lane) * DYP + e];
+            const float a = low ? dyl[((c * 4 + (lane >> 5)) * 64 + (lane & 31)) * 4 + e] : dyl[((c * 4 + (e >> 2)) * 64 + lane) * 4 + (e & 3)];
             acc[c][KF] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c][KF], 0, 0, 0);
           }
         }
@@ -3573,7 +3568,6 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
       if (e->train_f16 == 2) ap.out_l16 = reinterpret_cast<_Float16*>(ws + T.t_pool1_l16);
       if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys1);
     }
-    ap.y_tmajor = train_fwd16(e);
     ap.pool_h = e->sub;   // 2 x 40 tiles with 16-mel sub-bands (f16 modes): MaxPool2d((1, 5))
     if (taps && taps->drop1_mask_out && taps->drop1_p > 0.f) {   // Dropout drawn in the kernel
       MST_REQUIRE(taps->drop1_p < 1.f, "mst_encoder_forward_train: drop1_p must be in [0, 1)");
@@ -3672,7 +3666,6 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
     ApplyParams ap{y2, e->H1, aff2, pool_in, nullptr, 1.f, B, ns, T.tr2, T.tc2, e->FD, L.W2, (long long)B * ns * T.tr2 * T.tc2 * 4 * 64,
                    nullptr, nullptr, L.W1};
     if (e->train_f16 == 1) ap.y_scale = reinterpret_cast<const float*>(ws + T.t_ys2);
-    ap.y_tmajor = train_fwd16(e);
     hipLaunchKernelGGL((apply_kernel<2, 2>), dim3((unsigned)((ap.units + 255) / 256)), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -3763,7 +3756,6 @@ int mst_encoder_train_backward_apply_phase(const mst_encoder* e, int layer, int 
       p.dy = nullptr;
     }
   }
-  p.y_tmajor = train_bwd16(e);
   if (layer == 1) {
     p.yraw = reinterpret_cast<const float*>(ws + T.y1), p.aff = reinterpret_cast<const float2*>(ws + L.aff1);
     p.dy_acc = dy ? nullptr : reinterpret_cast<float*>(ws + T.y1);
