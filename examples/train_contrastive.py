@@ -51,6 +51,8 @@ def main(argv=None):
                     help="precision of the hand-written conv trunk: fp32 = exact fp32 MFMA; f16x3 = 3-term split-precision f16, "
                          "fp32-equivalent gradients at about twice the speed; f16 = float16 operands with fp32 accumulation (the "
                          "arithmetic of the reference's --use_amp step)")
+    ap.add_argument("--small-nets", choices=["hip", "torch"], default="hip",
+                    help="pooling head and FiLM MLP of the training step: hand-written forward / backward (csrc/head.hip) or the nn.Modules")
     a = ap.parse_args(argv)
     sr = 44100
     if a.synthetic:
@@ -64,6 +66,7 @@ def main(argv=None):
     model = MixingStyleEncoder(sr, 1024, 256, 128, 20, 10, 8, 768, feature_dim=64).to(dev).train()
     model.train_backend = a.train_backend
     model.train_precision = a.train_precision
+    model.small_nets_backend = a.small_nets
     deferred = torch.stack([deferred_features(64)] * (2 * a.batch_size)).to(dev)   # what the Dataset's feature slot carries
     crit = InfoNCELoss(0.1)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr)

@@ -368,6 +368,56 @@ int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* st
                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training forward / backward of the two small networks around the convolution trunk, fp32, deterministic
+ * (fixed-order reductions, no atomics), Dropout masks never stored -- a keep decision is a pure function of
+ * (seed, element index), Philox-2x32-10, re-derived by every kernel that needs it; p = 0 switches a Dropout off.
+ * All weight / gradient pointers are DEVICE tensors in state_dict layout (row-major nn.Linear weights [out][in]).
+ *
+ * Attention-pooling head = the reference's  F.dropout -> AttentionPooling  (src/model.py:118 for the Dropout in front,
+ * :187-211):  xd = Dropout_in(pool_in);  a = softmax_t(att2 . tanh(att0 xd_t + b0) + b2);  pooled = sum_t a_t xd_t;
+ * emb = Dropout_out(ReLU(proj pooled + bp)).     pool_in: dev [B][channels][frames];  emb: dev [B][embed_dim].
+ * `save` (mst_head_save_bytes) carries the activations the backward needs and must stay untouched until then.
+ * mst_head_backward: demb [B][embed_dim] -> the six parameter gradients (overwritten) and dpool_in [B][channels][frames].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mst_head_dims { int32_t channels, frames, attn_hidden, embed_dim; } mst_head_dims;   /* attn_hidden <= 256, channels <= 3072 */
+typedef struct mst_head_weights {
+  const float *att0_w, *att0_b;   /* attention.0   [A][C], [A] */
+  const float *att2_w, *att2_b;   /* attention.2   [1][A], [1] */
+  const float *proj_w, *proj_b;   /* projection.0  [E][C], [E] */
+} mst_head_weights;
+typedef struct mst_head_grads { float *att0_w, *att0_b, *att2_w, *att2_b, *proj_w, *proj_b; } mst_head_grads;
+size_t mst_head_save_bytes(const mst_head_dims* dims, int B, float drop_in_p);   /* (holds Dropout_in(pool_in) when drop_in_p > 0) */
+size_t mst_head_backward_workspace_bytes(const mst_head_dims* dims, int B);
+int mst_head_forward_train(const mst_head_dims* dims, const mst_head_weights* w, const float* pool_in, int B, float drop_in_p,
+                           uint64_t drop_in_seed, float drop_out_p, uint64_t drop_out_seed, float* emb, void* save,
+                           size_t save_bytes, void* stream);
+int mst_head_backward(const mst_head_dims* dims, const mst_head_weights* w, const float* pool_in, int B, float drop_in_p,
+                      uint64_t drop_in_seed, float drop_out_p, uint64_t drop_out_seed, const float* demb, const void* save,
+                      const mst_head_grads* grads, float* dpool_in, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The keep mask those Dropouts use, materialised: keep[i] = 1 iff element i (row-major index in the dropped tensor) survives
+ * Dropout(p) under `seed`; survivors are scaled by 1 / (1 - p).  For tests and for callers that want the mask itself.   */
+int mst_dropout_mask(float p, uint64_t seed, long long n, unsigned char* keep, void* stream);
+
+/* FiLM MLP = MixingFeatureEncoder.forward (src/model.py:410-464) in training mode:
+ * film = head(ReLU(mlp3(Dropout(ReLU(mlp0 feats)))));  feats: dev [B][feature_dim];  film: dev [B][out_dim] (n_sub * 192).
+ * mst_film_backward: dfilm [B][out_dim] -> the six parameter gradients (overwritten); the features get no gradient.      */
+typedef struct mst_film_dims { int32_t feature_dim, hidden, out_dim; } mst_film_dims;                /* feature_dim, hidden <= 2048 */
+typedef struct mst_film_weights {
+  const float *mlp0_w, *mlp0_b;   /* feature_mlp.0 [H][Fd], [H] */
+  const float *mlp3_w, *mlp3_b;   /* feature_mlp.3 [H][H], [H]  */
+  const float *head_w, *head_b;   /* film_head     [O][H], [O]  */
+} mst_film_weights;
+typedef struct mst_film_grads { float *mlp0_w, *mlp0_b, *mlp3_w, *mlp3_b, *head_w, *head_b; } mst_film_grads;
+size_t mst_film_save_bytes(const mst_film_dims* dims, int B);
+size_t mst_film_backward_workspace_bytes(const mst_film_dims* dims, int B);
+int mst_film_forward_train(const mst_film_dims* dims, const mst_film_weights* w, const float* feats, int B, float drop_p,
+                           uint64_t drop_seed, float* film, void* save, size_t save_bytes, void* stream);
+int mst_film_backward(const mst_film_dims* dims, const mst_film_weights* w, const float* feats, int B, float drop_p,
+                      const float* dfilm, const void* save, const mst_film_grads* grads, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * InfoNCE forward on (gathered) embeddings.  Replaces InfoNCELoss.forward src/loss.py:31-136.
  * emb: dev [N][D] fp32; labels: dev [N] int64; anchors [row0,row0+rows) are the local rows.
  * out: dev [2] = { sum over valid local anchors of -log(pos/(pos+neg+1e-8)), #valid anchors }.

@@ -70,6 +70,22 @@ class AugClip(C.Structure):
 
 
 # every symbol include/mst.h declares: (restype, argtypes)
+class HeadDims(C.Structure):
+    _fields_ = [("channels", C.c_int32), ("frames", C.c_int32), ("attn_hidden", C.c_int32), ("embed_dim", C.c_int32)]
+
+
+class HeadPtrs(C.Structure):   # mst_head_weights / mst_head_grads
+    _fields_ = [(k, C.c_void_p) for k in ("att0_w", "att0_b", "att2_w", "att2_b", "proj_w", "proj_b")]
+
+
+class FilmDims(C.Structure):
+    _fields_ = [("feature_dim", C.c_int32), ("hidden", C.c_int32), ("out_dim", C.c_int32)]
+
+
+class FilmPtrs(C.Structure):   # mst_film_weights / mst_film_grads
+    _fields_ = [(k, C.c_void_p) for k in ("mlp0_w", "mlp0_b", "mlp3_w", "mlp3_b", "head_w", "head_b")]
+
+
 SYMBOLS = {
     "mst_version": (C.c_int, []),
     "mst_last_error": (C.c_char_p, []),
@@ -103,6 +119,19 @@ SYMBOLS = {
     "mst_encoder_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "mst_encoder_forward_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                             C.POINTER(EncoderTrainTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "mst_head_save_bytes": (C.c_size_t, [C.POINTER(HeadDims), C.c_int, C.c_float]),
+    "mst_head_backward_workspace_bytes": (C.c_size_t, [C.POINTER(HeadDims), C.c_int]),
+    "mst_head_forward_train": (C.c_int, [C.POINTER(HeadDims), C.POINTER(HeadPtrs), C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_float,
+                                         C.c_uint64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_head_backward": (C.c_int, [C.POINTER(HeadDims), C.POINTER(HeadPtrs), C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_float,
+                                    C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(HeadPtrs), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_film_save_bytes": (C.c_size_t, [C.POINTER(FilmDims), C.c_int]),
+    "mst_film_backward_workspace_bytes": (C.c_size_t, [C.POINTER(FilmDims), C.c_int]),
+    "mst_film_forward_train": (C.c_int, [C.POINTER(FilmDims), C.POINTER(FilmPtrs), C.c_void_p, C.c_int, C.c_float, C.c_uint64,
+                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_film_backward": (C.c_int, [C.POINTER(FilmDims), C.POINTER(FilmPtrs), C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.POINTER(FilmPtrs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_encoder_update_params": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.c_void_p]),
     "mst_encoder_train_layout_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "mst_encoder_forward_train_in": (C.c_int, [C.c_void_p, C.POINTER(LogmelIn), C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -99,4 +99,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Philox-2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter-based, so every element's draw is a
+// pure function of (seed, element index) -- no generator state, no order dependence, reproducible for a given seed.
+__device__ __forceinline__ uint2 philox2x32(unsigned c0, unsigned c1, unsigned key) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
+    c0 = hi ^ key ^ c1;
+    c1 = lo;
+    key += 0x9E3779B9u;
+  }
+  return make_uint2(c0, c1);
+}
+// Dropout keep decision of element o: kept iff its 32-bit draw >= thresh (= p * 2^32).  (The pair partner o ^ 1 shares the block.)
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t o, unsigned thresh) {
+  const uint2 r = philox2x32((unsigned)(o >> 1), (unsigned)(o >> 33) ^ (unsigned)(seed >> 32), (unsigned)seed);
+  return ((o & 1) ? r.y : r.x) >= thresh;
+}
+
 }  // namespace mst

@@ -2016,23 +2016,7 @@ struct ApplyParams {
   unsigned drop_thresh;
 };
 
-// Philox-2x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3"): counter-based, so every element's draw is a
-// pure function of (seed, element index) -- no generator state, no order dependence, reproducible for a given seed.
-__device__ __forceinline__ uint2 philox2x32(unsigned c0, unsigned c1, unsigned key) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-    c0 = hi ^ key ^ c1;
-    c1 = lo;
-    key += 0x9E3779B9u;
-  }
-  return make_uint2(c0, c1);
-}
-// keep decision of element o (its pair partner o ^ 1 shares the block: callers with both may reuse it)
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, size_t o, unsigned thresh) {
-  const uint2 r = philox2x32((unsigned)(o >> 1), (unsigned)(o >> 33) ^ (unsigned)(seed >> 32), (unsigned)seed);
-  return ((o & 1) ? r.y : r.x) >= thresh;
-}
+using mst::dropout_keep;   // Philox-2x32-10 keyed dropout decisions (common.h)
 
 template <int LAYER, int SUB>
 __global__ __launch_bounds__(256) void apply_kernel(const ApplyParams p) {

