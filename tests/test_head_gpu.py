@@ -153,7 +153,7 @@ def test_training_step_is_a_descent_direction(precision):
     """End-to-end gradient check of the whole product step (stage A -> trunk -> head, FiLM MLP -> InfoNCE, everything in libmst.so,
     batch-statistics BatchNorm, Dropout off so that the function is the same at both points): moving every parameter by
     -eta * gradient changes the loss by -eta * |g|^2 to first order.  eta is chosen for a predicted decrease of 1 % of the loss; the
-    measured decrease must be within 30 % of it (curvature, max-pool / ReLU kinks)."""
+    measured decrease must be within 15 % of it (curvature, max-pool / ReLU kinks; measured 0.5 %)."""
     import cases
     from mst_amd.loss import InfoNCELoss
     from oracle import mel as omel
@@ -183,4 +183,4 @@ def test_training_step_is_a_descent_direction(precision):
     l1 = crit(m(stems, feats), labels)
     pred, got = eta * g2, l0.item() - l1.item()
     print(f"descent check [{precision}]: loss {l0.item():.5f} -> {l1.item():.5f}, predicted decrease {pred:.5f}, measured {got:.5f}")
-    assert 0.7 * pred <= got <= 1.3 * pred, (l0.item(), l1.item(), pred, got)
+    assert 0.85 * pred <= got <= 1.15 * pred, (l0.item(), l1.item(), pred, got)   # measured: 1.005
