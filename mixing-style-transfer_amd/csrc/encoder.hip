@@ -1503,17 +1503,24 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
     toff[st] = (tap / 7) * PC + tap % 7;
   }
 
-  h16x8 wreg[NWF], ph[NPF], pl[NPF];
+  // split-precision TRAINING forward (TERMS 3, MODE >= 1): the 52 registers that would hold the next chunk's weights through the
+  // MFMA phase do not exist next to the hi / lo fragments and the statistics (53 spilled registers, 2.4 ms instead of ~1.6):
+  // this instantiation fetches the chunk's weights AFTER the phase, straight through to LDS (their latency is exposed once per
+  // chunk, the registers are the fragments' own)
+  constexpr bool LATEW = TERMS == 3 && MODE >= 1;
+  h16x8 wreg[LATEW ? 1 : NWF], ph[NPF], pl[NPF];
   auto prefetch = [&](int q, const Tile& t) __attribute__((always_inline)) {
     const int chunk = q % NCH;
     const h16x8* wsrc = wfrag16 + ((size_t)t.band * NCH + chunk) * WVG;
+    if constexpr (!LATEW) {
 #pragma unroll
-    for (int i = 0; i < NWF; ++i) {
-      if constexpr (HLW == 2) {   // WV is a multiple of the block size: one base address + immediate offsets
-        wreg[i] = wsrc[tid + kConvThreads * i];
-      } else {
-        const int k = min(tid + kConvThreads * i, WV - 1);
-        wreg[i] = wsrc[((k >> 6) * 2) * 64 + (k & 63)];
+      for (int i = 0; i < NWF; ++i) {
+        if constexpr (HLW == 2) {   // WV is a multiple of the block size: one base address + immediate offsets
+          wreg[i] = wsrc[tid + kConvThreads * i];
+        } else {
+          const int k = min(tid + kConvThreads * i, WV - 1);
+          wreg[i] = wsrc[((k >> 6) * 2) * 64 + (k & 63)];
+        }
       }
     }
     const int row0 = 8 * t.tr - 3, col0 = 8 * t.tc - 3;
@@ -1545,9 +1552,15 @@ __global__ __launch_bounds__(kConvThreads) void conv2_f16x3_kernel(const ConvPar
   if (nq > 0) prefetch(0, nxt);
   for (int q = 0; q < nq; ++q) {
     __syncthreads();  // every wave is done with the previous chunk's weights
+    if constexpr (LATEW) {
+      const h16x8* wsrc = wfrag16 + ((size_t)nxt.band * NCH + q % NCH) * WVG;   // (nxt = the tile of this q)
 #pragma unroll
-    for (int i = 0; i < NWF; ++i)
-      if (WV % kConvThreads == 0 || tid + kConvThreads * i < WV) wres[tid + kConvThreads * i] = wreg[i];
+      for (int i = 0; i < NWF; ++i) wres[tid + kConvThreads * i] = wsrc[tid + kConvThreads * i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NWF; ++i)
+        if (WV % kConvThreads == 0 || tid + kConvThreads * i < WV) wres[tid + kConvThreads * i] = wreg[i];
+    }
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       const int e = lane + 64 * i;
