@@ -272,6 +272,15 @@ int mst_encoder_update_trunk_params(mst_encoder* enc, const float* conv1_w, cons
                                     const float* bn1_b, const float* conv2_w, const float* conv2_b,
                                     const float* bn2_w, const float* bn2_b, void* stream);
 
+/* Running statistics of BatchNorm layer 1 / 2 after mst_encoder_forward_train, as nn.BatchNorm2d updates them in training mode
+ * (src/model.py:107-125): running = (1 - momentum) running + momentum batch (unbiased batch variance), num_batches_tracked += 1.
+ * running_mean / running_var: dev [n_sub][C] (the sub-bands' buffers stacked), num_batches_tracked: dev int64 [n_sub];
+ * reads the batch statistics the forward left in `workspace` (same buffer, B, frames); cross_rank != 0: the element count is taken
+ * from the summed clip-count word of the statistics buffer (mst_encoder_train_stats_buffer), i.e. the GLOBAL batch.  One launch. */
+int mst_encoder_train_update_running_stats(const mst_encoder* enc, int layer, int B, int frames, float* running_mean,
+                                           float* running_var, long long* num_batches_tracked, float momentum, int cross_rank,
+                                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Device-side refresh of EVERY parameter table of an existing encoder -- what a trainer calls before a validation pass after
  * optimizer steps (src/train.py:388-427 follows :292-296): `w` has mst_encoder_create's fields, but every pointer is a DEVICE
  * tensor in state_dict layout (the sub-band tensors stacked over the bands).  Fragment swizzles, the eval BatchNorm fold, the

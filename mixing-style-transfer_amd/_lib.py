@@ -132,6 +132,8 @@ SYMBOLS = {
                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_film_backward": (C.c_int, [C.POINTER(FilmDims), C.POINTER(FilmPtrs), C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                     C.POINTER(FilmPtrs), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_encoder_train_update_running_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                         C.c_float, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_encoder_update_params": (C.c_int, [C.c_void_p, C.POINTER(EncoderWeights), C.c_void_p]),
     "mst_encoder_train_layout_supported": (C.c_int, [C.c_void_p, C.c_int]),
     "mst_encoder_forward_train_in": (C.c_int, [C.c_void_p, C.POINTER(LogmelIn), C.c_int, C.c_void_p, C.c_int, C.c_void_p,

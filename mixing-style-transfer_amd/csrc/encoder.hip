@@ -3452,8 +3452,8 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
   const int grid = e->num_cus;
   hipError_t err;
   if (run_a) {
-  MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (size_t)ns * 32 * 2 * sizeof(mst::DetAcc), st));
-  MST_HIP_CHECK(hipMemsetAsync(stats2, 0, (size_t)ns * 64 * 2 * sizeof(mst::DetAcc), st));
+  // (stats1 and stats2 are neighbours in the workspace: one fill)
+  MST_HIP_CHECK(hipMemsetAsync(stats1, 0, (T.stats2 - T.stats1) + (size_t)ns * 64 * 2 * sizeof(mst::DetAcc), st));
   if (phase != 0)   // cross-rank statistics: this rank's clip count rides with each layer's sums
     hipLaunchKernelGGL(set_clips_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<long long*>(stats1 + ns * 32 * 2),
                        reinterpret_cast<long long*>(stats2 + ns * 64 * 2), (long long)B);
@@ -3819,6 +3819,57 @@ int mst_encoder_train_backward_apply_phase(const mst_encoder* e, int layer, int 
   return MST_OK;
 }
 
+namespace {
+// six small device-to-device copies in one launch (blockIdx.y = which)
+struct CopySix {
+  float* dst[6];
+  const float* src[6];
+  int n[6];
+};
+__global__ void copy_six_kernel(const CopySix c) {
+  const int k = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < c.n[k]) c.dst[k][i] = c.src[k][i];
+}
+
+// running statistics of a BatchNorm layer after a training forward, as nn.BatchNorm2d updates them (src/model.py:107-125 under
+// model.train()): running = (1 - m) running + m batch, the batch variance unbiased (count / (count - 1)); stat = (mean, 1/sqrt(biased
+// var + eps)) as the training forward left it; clips != NULL: count = clips[0] * per_clip (cross-rank statistics), else `count`
+__global__ void bn_running_update_kernel(const float2* __restrict__ stat, float* __restrict__ rmean, float* __restrict__ rvar,
+                                         long long* __restrict__ nbatches, int n, int nsub, float momentum, float eps, double count,
+                                         const long long* __restrict__ clips, double per_clip) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nsub) nbatches[i] += 1;
+  if (i >= n) return;
+  const double cnt = clips ? (double)clips[0] * per_clip : count;
+  const float corr = (float)(cnt / fmax(cnt - 1.0, 1.0));
+  const float2 s = stat[i];
+  const float var = __fmul_rn(__fsub_rn(__frcp_rn(__fmul_rn(s.y, s.y)), eps), corr);
+  rmean[i] = __fadd_rn(__fmul_rn(rmean[i], 1.f - momentum), __fmul_rn(s.x, momentum));
+  rvar[i] = __fadd_rn(__fmul_rn(rvar[i], 1.f - momentum), __fmul_rn(var, momentum));
+}
+}  // namespace
+
+int mst_encoder_train_update_running_stats(const mst_encoder* e, int layer, int B, int frames, float* running_mean, float* running_var,
+                                           long long* num_batches_tracked, float momentum, int cross_rank, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && (layer == 1 || layer == 2) && running_mean && running_var && num_batches_tracked && B > 0 && frames >= 20,
+              "mst_encoder_train_update_running_stats: bad argument");
+  const TrainLayout T = train_layout(e, B, frames);
+  if (!workspace || workspace_bytes < T.total)
+    return mst::fail(MST_ENOMEM, "mst_encoder_train_update_running_stats: workspace %zu B < required %zu B", workspace_bytes, T.total);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  const int ns = e->cfg.n_subbands, cout = layer == 1 ? 32 : 64;
+  const double per_clip = layer == 1 ? (double)e->cfg.split_size * frames : (double)e->H1 * T.base.W1;
+  const mst::DetAcc* stats = reinterpret_cast<const mst::DetAcc*>(ws + (layer == 1 ? T.stats1 : T.stats2));
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((ns * cout + 255) / 256), dim3(256), 0, st,
+                     reinterpret_cast<const float2*>(ws + (layer == 1 ? T.bn1 : T.bn2)), running_mean, running_var, num_batches_tracked,
+                     ns * cout, ns, momentum, e->cfg.bn_eps, (double)B * per_clip,
+                     cross_rank ? reinterpret_cast<const long long*>(stats + ns * cout * 2) : nullptr, per_clip);
+  MST_HIP_CHECK(hipGetLastError());
+  return MST_OK;
+}
+
 int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const float* conv1_b, const float* bn1_w,
                                     const float* bn1_b, const float* conv2_w, const float* conv2_b, const float* bn2_w,
                                     const float* bn2_b, void* stream) {
@@ -3854,10 +3905,10 @@ int mst_encoder_update_trunk_params(mst_encoder* e, const float* conv1_w, const 
                        reinterpret_cast<_Float16*>(e->w2dfrag16), ns, 32, 64, e->train_f16 == 2 ? 2 : 1, 1);
     MST_HIP_CHECK(hipGetLastError());
   }
-  const struct { float* dst; const float* src; int n; } cp[] = {
-      {e->c1b, conv1_b, ns * 32}, {e->bn1w, bn1_w, ns * 32}, {e->bn1b, bn1_b, ns * 32},
-      {e->c2b, conv2_b, ns * 64}, {e->bn2w, bn2_w, ns * 64}, {e->bn2b, bn2_b, ns * 64}};
-  for (const auto& c : cp) MST_HIP_CHECK(hipMemcpyAsync(c.dst, c.src, (size_t)c.n * 4, hipMemcpyDeviceToDevice, st));
+  CopySix c6{{e->c1b, e->bn1w, e->bn1b, e->c2b, e->bn2w, e->bn2b}, {conv1_b, bn1_w, bn1_b, conv2_b, bn2_w, bn2_b},
+             {ns * 32, ns * 32, ns * 32, ns * 64, ns * 64, ns * 64}};
+  hipLaunchKernelGGL(copy_six_kernel, dim3((ns * 64 + 255) / 256, 6), dim3(256), 0, st, c6);   // one launch instead of six copies
+  MST_HIP_CHECK(hipGetLastError());
   return MST_OK;
 }
 

@@ -276,11 +276,11 @@ class HipEncoder:
         return self._ws_view(off.value, 4, torch.int32)
 
     def forward_train(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, sync=None, drop1_seed=None,
-                      want_pool1=True):
+                      want_pool1=True, want_film=True, want_bn=True):
         """`forward_train_steps` run to completion; `sync` (an object with `.world`, `.sum(int64 tensor)`, `.max(int32 tensor)`,
         e.g. DistSync) adds the ranks' BatchNorm statistics between the phases; None = this process only."""
         steps = self.forward_train_steps(logmel, feats, film, head, drop1_mask, drop1_p, sync.world if sync is not None else 0,
-                                         drop1_seed, want_pool1)
+                                         drop1_seed, want_pool1, want_film, want_bn)
         try:
             while True:
                 kind, view = next(steps)
@@ -304,7 +304,7 @@ class HipEncoder:
         return lay if _lib.lib().mst_encoder_train_layout_supported(self._h, lay) else _lib.LOGMEL_REF
 
     def forward_train_steps(self, logmel, feats=None, film=None, head=True, drop1_mask=None, drop1_p=0.0, world=0,
-                            drop1_seed=None, want_pool1=True):
+                            drop1_seed=None, want_pool1=True, want_film=True, want_bn=True):
         """Generator form of the train-mode forward.  world = 0: one call of `mst_encoder_forward_train`, nothing is yielded.
         world >= 1: the three phases of include/mst.h; after phase 1 and 2 it yields ("sum", int64 view of that layer's
         statistics accumulators), which the caller must all-reduce (SUM) over its `world` ranks before resuming.
@@ -331,10 +331,11 @@ class HipEncoder:
         p1_shape = (B, self.n_sub, 32, self.split // max(1, self.split // 10), W1)
         if not want_pool1 and not self.train_f16:
             raise _lib.MstError("forward_train(want_pool1=False) needs a float16 training mode (the fp32 conv2 reads the fp32 pool1)")
-        out = {"film": torch.empty(B, self.n_sub * 192, device=dev),
+        out = {"film": torch.empty(B, self.n_sub * 192, device=dev) if want_film else None,
                "pool1": torch.empty(p1_shape, device=dev) if want_pool1 else None,
                "pool_in": torch.empty(B, 64 * self.n_sub * self.freq_dim, W1 // 4, device=dev),
-               "bn1": torch.empty(self.n_sub, 32, 2, device=dev), "bn2": torch.empty(self.n_sub, 64, 2, device=dev)}
+               "bn1": torch.empty(self.n_sub, 32, 2, device=dev) if want_bn else None,
+               "bn2": torch.empty(self.n_sub, 64, 2, device=dev) if want_bn else None}
         film_c = film.detach().contiguous().float() if film is not None else None
         feats_c = feats.contiguous().float() if feats is not None else None
         mask_c = drop1_mask.contiguous() if drop1_mask is not None else None
@@ -356,6 +357,28 @@ class HipEncoder:
             if phase in (1, 2):
                 yield "sum", self.stats_view(phase, B, Fr)
         return emb, out
+
+    def _zero_bias_grad(self, c, dev):
+        """(n_sub, c) zeros, cached: the gradient of a convolution bias in front of a batch-statistics BatchNorm.  Handed out as a
+        gradient every step; nothing writes to it (optimizers read gradients, gradient clipping scales zeros to zeros)."""
+        z = self.__dict__.setdefault("_zero_cache", {})
+        k = (c, str(dev))
+        if k not in z:
+            z[k] = torch.zeros(self.n_sub, c, device=dev)
+        return z[k]
+
+    def update_running_stats(self, layer, B, frames, running_mean, running_var, num_batches_tracked, momentum, cross_rank=False):
+        """nn.BatchNorm2d's running-statistics update of layer 1 / 2 from the batch statistics the last `forward_train` left in its
+        workspace (`mst_encoder_train_update_running_stats`: one launch; stacked buffers (n_sub, C) / (n_sub,) int64)."""
+        L = _lib.lib()
+        need = L.mst_encoder_train_workspace_bytes(self._h, B, frames)
+        dev = running_mean.device
+        assert running_mean.is_contiguous() and running_var.is_contiguous() and num_batches_tracked.dtype == torch.int64
+        with torch.cuda.device(dev):
+            _lib.check(L.mst_encoder_train_update_running_stats(self._h, layer, B, frames, _lib.dptr(running_mean), _lib.dptr(running_var),
+                                                                _lib.dptr(num_batches_tracked), float(momentum), int(bool(cross_rank)),
+                                                                _lib.dptr(self._ws_train), need, _lib.stream_ptr(dev)),
+                       "mst_encoder_train_update_running_stats")
 
     TRAIN_MODES = {"fp32": 0, "f16": 1, "f16x3": 2}
 
@@ -546,7 +569,7 @@ class _HipTrunk(torch.autograd.Function):
     last_timing = None
 
     @staticmethod
-    def forward(ctx, enc, logmel, film, flat, drop_p, sync, reducer, *params):
+    def forward(ctx, enc, logmel, film, flat, drop_p, sync, reducer, want_bn, *params):
         """flat: the 8 parameter families (conv1.weight, conv1.bias, bn1.weight, bn1.bias, conv2.*, bn2.*) stacked over the
         sub-bands -- the storage the per-band Parameters are views of (MixingStyleEncoder._trunk_flat), so no stack kernels run;
         params: those Parameters themselves, family-major, only so that autograd routes the gradients to them (the backward
@@ -555,8 +578,15 @@ class _HipTrunk(torch.autograd.Function):
             B, Fr = logmel.B, logmel.frames
         else:
             B, _, M, Fr = logmel.shape
-        trunk = tuple(b.clone() for b in flat)   # this pass's parameter snapshot (8 small copies; an optimizer step or another
-        #                                          pass may rewrite the live storage before this pass's backward runs)
+        # this pass's parameter snapshot (an optimizer step or another pass may rewrite the live storage before this pass's backward
+        # runs): ONE copy when the eight families live in one storage (MixingStyleEncoder._trunk_flat), else one per family
+        base = getattr(flat[0], "_base", None)
+        if base is not None and all(getattr(b, "_base", None) is base for b in flat):
+            snap = base.clone()
+            off = [b.storage_offset() - base.storage_offset() for b in flat]
+            trunk = tuple(snap[o:o + b.numel()].view(b.shape) for o, b in zip(off, flat))
+        else:
+            trunk = tuple(b.clone() for b in flat)
         ctx.n_sub = flat[0].shape[0]
         enc.update_trunk_params(*trunk)
         # which forward pass's parameters the encoder's weight fragments hold: a MONOTONIC pass counter names the passes, the
@@ -573,7 +603,7 @@ class _HipTrunk(torch.autograd.Function):
         enc._ws_train = None
         # (float16 modes: conv2 and its weight gradient read the float16 pool1 planes in the workspace -- no fp32 pool1 tensor)
         _, t = enc.forward_train(logmel, film=film, head=False, drop1_p=drop_p, sync=sync, drop1_seed=seed,
-                                 want_pool1=not enc.train_f16)
+                                 want_pool1=not enc.train_f16, want_film=False, want_bn=want_bn)
         mask = t.get("drop1_mask")
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync, ctx.reducer = enc, drop_p, (B, Fr), sync, reducer
         ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode
@@ -584,11 +614,13 @@ class _HipTrunk(torch.autograd.Function):
         else:
             ctx.lm_layout = None
             ctx.save_for_backward(logmel, None, t["pool1"], mask, enc._ws_train, *trunk)
+        if not want_bn:   # (the caller updates the running statistics from the workspace: mst_encoder_train_update_running_stats)
+            return t["pool_in"]
         ctx.mark_non_differentiable(t["bn1"], t["bn2"])
         return t["pool_in"], t["bn1"], t["bn2"]
 
     @staticmethod
-    def backward(ctx, dpool_in, _d1, _d2):
+    def backward(ctx, dpool_in, _d1=None, _d2=None):
         enc, (B, Fr) = ctx.enc, ctx.dims
         logmel, lm_lo, p1, mask, ws, *trunk = ctx.saved_tensors
         dev = logmel.device
@@ -618,7 +650,7 @@ class _HipTrunk(torch.autograd.Function):
         dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr, sync=sync)
         mark("apply_bwd2")
         gw2 = enc.conv2_wgrad(p1, B, Fr)          # weight gradient on dy2 in accumulator order
-        gb2 = torch.zeros(ns, 64, device=dev)   # exactly 0 in front of a batch-statistics BatchNorm
+        gb2 = enc._zero_bias_grad(64, dev)      # exactly 0 in front of a batch-statistics BatchNorm (a cached constant)
         mark("conv2_wgrad")
         dbn2w, dbn2b = dbn2[..., 0], dbn2[..., 1]   # contiguous planes (no copies)
         reducer = ctx.reducer
@@ -629,7 +661,7 @@ class _HipTrunk(torch.autograd.Function):
         _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
         mark("apply_bwd1")
         gw1 = enc.conv1_wgrad(logmel, B, Fr)
-        gb1 = torch.zeros(ns, 32, device=dev)
+        gb1 = enc._zero_bias_grad(32, dev)
         mark("conv1_wgrad")
         if _TRAIN_TIMING:
             torch.cuda.synchronize()
@@ -638,7 +670,7 @@ class _HipTrunk(torch.autograd.Function):
         if reducer is not None:
             reducer.reduce_stacked("conv1", [gw1, gb1, dbn1w, dbn1b])
         fams = (gw1, gb1, dbn1w, dbn1b, gw2, gb2, dbn2w, dbn2b)
-        return (None, None, dfilm, None, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
+        return (None, None, dfilm, None, None, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
 
 
 def _seed64():
@@ -793,15 +825,20 @@ class MixingStyleEncoder(nn.Module):
             b.shape[0] == ns and params[f * ns].data_ptr() == b.data_ptr() and
             params[f * ns + ns - 1].data_ptr() == b[ns - 1].data_ptr() and params[f * ns].dtype == b.dtype
             for f, b in enumerate(flat))
-        if not ok:
+        if not ok:   # ONE storage for the eight families (a pass's parameter snapshot is then a single copy), each family a view
             flat = []
             with torch.no_grad():
-                for f in range(8):
-                    ps = params[f * ns:(f + 1) * ns]
-                    buf = torch.stack([q.detach() for q in ps])
+                fams = [params[f * ns:(f + 1) * ns] for f in range(8)]
+                sizes = [ns * ps[0].numel() for ps in fams]
+                base = torch.empty(sum(sizes), dtype=fams[0][0].dtype, device=fams[0][0].device)
+                o = 0
+                for ps, n in zip(fams, sizes):
+                    buf = base[o:o + n].view((ns,) + tuple(ps[0].shape))
+                    torch.stack([q.detach() for q in ps], out=buf)
                     for i, q in enumerate(ps):
                         q.data = buf[i]
                     flat.append(buf)
+                    o += n
             self._trunk_flat_bufs = flat
         return flat, params
 
@@ -851,25 +888,27 @@ class MixingStyleEncoder(nn.Module):
                 sync = DistSync()
         elif self.sync_bn:
             sync = self.sync_bn
-        pool_in, bn1, bn2 = _HipTrunk.apply(enc, logmel, flat, trunk_flat, float(p), sync, getattr(self, "_grad_reducer", None),
-                                            *trunk_params)
-        with torch.no_grad():   # running statistics, as nn.BatchNorm2d does in training mode (unbiased variance)
-            B, Fr = (logmel.B, logmel.frames) if isinstance(logmel, LogMel) else (logmel.shape[0], logmel.shape[-1])
-            if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different
-                B = enc.stats_view(1, B, Fr)[-2].to(torch.float64)   # numbers of clips); a device scalar: no host sync
-            for stat, name, n in ((bn1, "bn1", B * (ae.split_size * Fr)), (bn2, "bn2", B * ((ae.split_size // enc.sub) * (Fr // 5)))):
-                corr = (n / torch.clamp(n - 1, min=1)).float() if torch.is_tensor(n) else n / max(n - 1, 1)
-                mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * corr
-                bns = [getattr(c, name) for c in cn]
-                moms = {bn.momentum if bn.momentum is not None else 0.1 for bn in bns}
-                if len(moms) == 1:   # the buffers are views of stacked tensors: five launches per layer instead of 3 x n_sub
-                    m = moms.pop()
+        # running statistics, as nn.BatchNorm2d updates them in training mode (unbiased variance): one launch per layer from the batch
+        # statistics in the pass's workspace when the sub-bands share one momentum (they do in the reference), else per module
+        mom = {name: {bn.momentum if bn.momentum is not None else 0.1 for bn in (getattr(c, name) for c in cn)} for name in ("bn1", "bn2")}
+        fused_stats = all(len(v) == 1 for v in mom.values())
+        out = _HipTrunk.apply(enc, logmel, flat, trunk_flat, float(p), sync, getattr(self, "_grad_reducer", None), not fused_stats,
+                              *trunk_params)
+        B, Fr = (logmel.B, logmel.frames) if isinstance(logmel, LogMel) else (logmel.shape[0], logmel.shape[-1])
+        with torch.no_grad():
+            if fused_stats:
+                pool_in = out
+                for layer, name in ((1, "bn1"), (2, "bn2")):
                     rm, rv, nb = self._bn_flat(name)
-                    rm.mul_(1 - m).add_(mean, alpha=m)
-                    rv.mul_(1 - m).add_(var, alpha=m)
-                    nb.add_(1)
-                else:
-                    for i, bn in enumerate(bns):
+                    enc.update_running_stats(layer, B, Fr, rm, rv, nb, next(iter(mom[name])), cross_rank=sync is not None)
+            else:
+                pool_in, bn1, bn2 = out
+                if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different
+                    B = enc.stats_view(1, B, Fr)[-2].to(torch.float64)   # numbers of clips); a device scalar: no host sync
+                for stat, name, n in ((bn1, "bn1", B * (ae.split_size * Fr)), (bn2, "bn2", B * ((ae.split_size // enc.sub) * (Fr // 5)))):
+                    corr = (n / torch.clamp(n - 1, min=1)).float() if torch.is_tensor(n) else n / max(n - 1, 1)
+                    mean, var = stat[..., 0], (1.0 / stat[..., 1] ** 2 - cn[0].bn1.eps) * corr
+                    for i, bn in enumerate(getattr(c, name) for c in cn):
                         m = bn.momentum if bn.momentum is not None else 0.1
                         bn.running_mean.mul_(1 - m).add_(mean[i], alpha=m)
                         bn.running_var.mul_(1 - m).add_(var[i], alpha=m)
