@@ -359,13 +359,9 @@ class HipEncoder:
         return emb, out
 
     def _zero_bias_grad(self, c, dev):
-        """(n_sub, c) zeros, cached: the gradient of a convolution bias in front of a batch-statistics BatchNorm.  Handed out as a
-        gradient every step; nothing writes to it (optimizers read gradients, gradient clipping scales zeros to zeros)."""
-        z = self.__dict__.setdefault("_zero_cache", {})
-        k = (c, str(dev))
-        if k not in z:
-            z[k] = torch.zeros(self.n_sub, c, device=dev)
-        return z[k]
+        """(n_sub, c) zeros: the gradient of a convolution bias in front of a batch-statistics BatchNorm.  A fresh tensor every time:
+        it becomes a `.grad` the caller owns and may modify in place."""
+        return torch.zeros(self.n_sub, c, device=dev)
 
     def update_running_stats(self, layer, B, frames, running_mean, running_var, num_batches_tracked, momentum, cross_rank=False):
         """nn.BatchNorm2d's running-statistics update of layer 1 / 2 from the batch statistics the last `forward_train` left in its
@@ -650,7 +646,7 @@ class _HipTrunk(torch.autograd.Function):
         dy2, dbn2 = enc.backward_apply(2, dpool_in.contiguous(), dfilm, B, Fr, sync=sync)
         mark("apply_bwd2")
         gw2 = enc.conv2_wgrad(p1, B, Fr)          # weight gradient on dy2 in accumulator order
-        gb2 = enc._zero_bias_grad(64, dev)      # exactly 0 in front of a batch-statistics BatchNorm (a cached constant)
+        gb2 = enc._zero_bias_grad(64, dev)      # exactly 0 in front of a batch-statistics BatchNorm
         mark("conv2_wgrad")
         dbn2w, dbn2b = dbn2[..., 0], dbn2[..., 1]   # contiguous planes (no copies)
         reducer = ctx.reducer
