@@ -1220,8 +1220,8 @@ def test_dropout_drawn_inside_the_pooling_epilogue():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-@pytest.mark.parametrize("precision", ["f16", "f16x3"])
-def test_non_finite_values_stay_visible_in_f16_training(precision):
+@pytest.mark.parametrize("precision", ["fp32", "f16", "f16x3"])
+def test_non_finite_values_stay_visible_in_training(precision):
     """A NaN that enters the trunk (here: one NaN sample in a stem) must come out as non-finite embeddings and gradients, as it
     does under the reference's autocast step -- whose GradScaler then skips the optimizer step (src/train.py:251-262).  The
     float16 stores of the training kernels saturate FINITE values only; a clamp that maps NaN to -65504 would hand the trainer
