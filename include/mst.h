@@ -102,7 +102,7 @@ typedef struct mst_melfeat_io {
   int32_t pcm16;
   int32_t layout;         /* MST_LOGMEL_*: layout of `logmel`                                                        */
   void* logmel;           /* dev, may be NULL (features only)                                                        */
-  void* logmel_lo;        /* dev, MST_LOGMEL_CM16 only: the low parts                                                 */
+  void* logmel_lo;        /* dev, MST_LOGMEL_CM16 only: the low parts; NULL = write the high parts alone (plain f16) */
   uint32_t* absmax;       /* optional dev [B]: max |log-mel| of every clip as float bits (zeroed by the call) -- the    */
                           /* range bound of the float16 convolutions, so that no separate pass reads the log-mel      */
   float* feats;           /* dev [B][feature_dim], may be NULL                                                       */

@@ -1489,7 +1489,6 @@ int mst_melfeat_forward_io(const mst_plan* p, const mst_melfeat_io* io, int B, i
   MST_REQUIRE(mst_plan_layout_supported(p, io->layout),
               "mst_melfeat_forward_io: layout %d is not available for this plan (n_fft %d, hop %d: query mst_plan_layout_supported)",
               io->layout, p->n_fft, p->hop);
-  MST_REQUIRE(io->layout != MST_LOGMEL_CM16 || !io->logmel || io->logmel_lo, "mst_melfeat_forward_io: MST_LOGMEL_CM16 needs logmel_lo");
   MST_REQUIRE(io->layout == MST_LOGMEL_REF || !io->logmel || (reinterpret_cast<uintptr_t>(io->logmel) & 15) == 0,
               "mst_melfeat_forward_io: channel-minor log-mel must be 16-byte aligned");
   MST_REQUIRE(io->layout != MST_LOGMEL_CM16 || !io->logmel_lo || (reinterpret_cast<uintptr_t>(io->logmel_lo) & 15) == 0,

@@ -66,8 +66,9 @@ def melscale_fbanks_htk(n_freqs: int, n_mels: int, sample_rate: int) -> torch.Te
 class LogMel:
     """A log-mel batch in one of the ENCODER-INTERNAL channel-minor layouts that stage A writes directly (include/mst.h
     MST_LOGMEL_CM32 / CM16): `data` (B, frames, n_mels, 8) fp32, or float16 high parts with the low parts in `lo`;
-    `absmax` (B,) int32 = max |log-mel| per clip as float bits (the range bound of the float16 convolutions).  Only
-    `HipEncoder.forward` consumes it; `to_reference()` gives the reference's (B, 8, n_mels, frames) tensor."""
+    `absmax` (B,) int32 = max |log-mel| per clip as float bits (the range bound of the float16 convolutions).  `lo` may be
+    None when only the plain-float16 kernels will read it (they use the high parts alone).  `HipEncoder.forward` and the float16
+    training trunk consume it; `to_reference()` gives the reference's (B, 8, n_mels, frames) tensor."""
 
     def __init__(self, layout, data, lo=None, absmax=None):
         self.layout, self.data, self.lo, self.absmax = layout, data, lo, absmax
@@ -75,6 +76,9 @@ class LogMel:
         self.device = data.device
 
     def to_reference(self):
+        if self.layout == _lib.LOGMEL_CM16 and self.lo is None:
+            raise _lib.MstError("this LogMel holds the float16 HIGH parts only (what the plain-float16 kernels read): the fp32 "
+                                "log-mel cannot be recovered from it -- ask stage A for the reference layout instead")
         x = self.data.float() if self.lo is None else self.data.float() + self.lo.float()
         return x.permute(0, 3, 2, 1).contiguous()
 
@@ -117,7 +121,7 @@ class MelFeatPlan:
         """Whether stage A writes `layout` (_lib.LOGMEL_*) directly for this configuration."""
         return bool(_lib.lib().mst_plan_layout_supported(self._h, int(layout)))
 
-    def _run(self, ptrs4, stride, pcm16, B, T, dev, want_logmel, want_feats, layout, want_absmax):
+    def _run(self, ptrs4, stride, pcm16, B, T, dev, want_logmel, want_feats, layout, want_absmax, want_lo=True):
         F = self.frames(T)
         logmel = lo = absmax = None
         if want_logmel:
@@ -127,7 +131,7 @@ class MelFeatPlan:
                 logmel = torch.empty(B, F, self.n_mels, 8, dtype=torch.float32, device=dev)
             else:
                 logmel = torch.empty(B, F, self.n_mels, 8, dtype=torch.float16, device=dev)
-                lo = torch.empty_like(logmel)
+                lo = torch.empty_like(logmel) if want_lo else None   # (plain-float16 consumers read the high parts only)
             if want_absmax and layout != _lib.LOGMEL_REF:
                 absmax = torch.empty(B, dtype=torch.int32, device=dev)
         feats = torch.empty(B, self.feature_dim, dtype=torch.float32, device=dev) if want_feats else None
@@ -141,7 +145,7 @@ class MelFeatPlan:
             logmel = LogMel(layout, logmel, lo, absmax)
         return logmel, feats
 
-    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True, layout=_lib.LOGMEL_REF, want_absmax=False):
+    def forward_stems(self, stems_dict, want_logmel=True, want_feats=True, layout=_lib.LOGMEL_REF, want_absmax=False, want_lo=True):
         """{stem: (B,2,T) | (2,T)} fp32 CUDA -> (logmel, feats) without concatenating the stems: the kernel reads the
         four tensors in place (views of one packed (B,8,T) tensor work too, any common clip stride).
         layout: _lib.LOGMEL_REF -> the reference's (B, 8, n_mels, frames) tensor; LOGMEL_CM32 / CM16 -> a `LogMel` in the
@@ -158,13 +162,13 @@ class MelFeatPlan:
             and dt in (torch.float32, torch.int16)
         if not ok:
             if all(q.dtype == torch.int16 for q in parts):
-                return self.forward(torch.cat(parts, dim=1), want_logmel, want_feats, layout, want_absmax)
-            return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats, layout, want_absmax)
+                return self.forward(torch.cat(parts, dim=1), want_logmel, want_feats, layout, want_absmax, want_lo)
+            return self.forward(torch.cat([q.float() for q in parts], dim=1), want_logmel, want_feats, layout, want_absmax, want_lo)
         stride = parts[0].stride(0) if B > 1 else 2 * T
         return self._run([q.data_ptr() for q in parts], stride, dt == torch.int16, B, T, parts[0].device, want_logmel,
-                         want_feats, layout, want_absmax)
+                         want_feats, layout, want_absmax, want_lo)
 
-    def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True, layout=_lib.LOGMEL_REF, want_absmax=False):
+    def forward(self, stems8: torch.Tensor, want_logmel=True, want_feats=True, layout=_lib.LOGMEL_REF, want_absmax=False, want_lo=True):
         """stems8 (B, 8, T) CUDA, fp32 or int16 PCM (value = s / 32768) -> (logmel (B,8,M,F) | LogMel | None, feats (B,Fd) | None)."""
         if not stems8.is_cuda:
             raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
@@ -185,7 +189,7 @@ class MelFeatPlan:
             return logmel, feats
         es = x.element_size()
         return self._run([x.data_ptr() + 2 * s * T * es for s in range(4)], 8 * T, pcm16, B, T, x.device, want_logmel,
-                         want_feats, layout, want_absmax)
+                         want_feats, layout, want_absmax, want_lo)
 
 
 def stems_to_tensor(stems_dict) -> torch.Tensor:

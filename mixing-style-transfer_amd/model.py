@@ -1011,20 +1011,20 @@ class MixingStyleEncoder(nn.Module):
         # (whole-line stores there, 256-byte runs / ready-made float16 operands for conv1), and so does the hand-written
         # training trunk in its float16 modes; every other path -- fp32 training, the PyTorch backend -- gets the reference's
         # (B, 8, n_mels, frames) tensor
-        layout = _lib.LOGMEL_REF
+        layout, want_lo = _lib.LOGMEL_REF, True
         auto = self._needs_autograd(mixing_features)
         if self.encoder_backend == "hip" and not self.training and not auto:
             want = self.hip_encoder().preferred_layout()
             if plan.supports_layout(want):
-                layout = want
+                layout, want_lo = want, self.hip_encoder().mode != 3   # (plain float16: the high parts alone)
         elif self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict") and \
                 self.audio_encoder.split_size // 10 in (1, 2):
             # the float16 training trunk reads stage A's float16 planes (conv1 forward and its weight gradient)
             want = self._train_encoder().train_layout()
             if plan.supports_layout(want):
-                layout = want
+                layout, want_lo = want, self._train_encoder().train_mode != 1   # (f16 mode: the high parts alone)
         with torch.no_grad():
-            logmel, feats = plan.forward_stems(stems_dict, True, has_feats, layout, want_absmax=layout == _lib.LOGMEL_CM16)
+            logmel, feats = plan.forward_stems(stems_dict, True, has_feats, layout, want_absmax=layout == _lib.LOGMEL_CM16, want_lo=want_lo)
         mf = mixing_features.to(logmel.device)
         if feats is not None:
             mf = torch.where(is_deferred(mf), feats.to(mf.dtype), mf)

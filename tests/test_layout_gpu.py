@@ -319,3 +319,43 @@ def test_eval_encoder_is_refreshed_on_the_device_after_parameter_updates(precisi
         assert torch.equal(e_after, e_fresh)
     else:   # the L1 norms behind the range scales are summed in another order on the device: at most a last-bit difference
         assert (e_after - e_fresh).abs().max().item() <= 2e-6 * e_fresh.abs().max().item()
+
+
+def test_plain_float16_consumers_get_the_high_parts_alone():
+    """`forward_stems(..., LOGMEL_CM16, want_lo=False)`: stage A writes the float16 high parts only (the plain-float16 eval mode and
+    the f16 training mode read nothing else) -- same bits as with the low parts, a quarter of the log-mel bytes less to write and to
+    keep alive; such a LogMel cannot be turned back into the fp32 tensor and says so; the module asks for it by itself."""
+    from mst_amd import _lib
+    plan = _plan()
+    d = _stems(2, 44100, seed=8)
+    full, _ = plan.forward_stems(d, True, False, _lib.LOGMEL_CM16, want_absmax=True)
+    hi, _ = plan.forward_stems(d, True, False, _lib.LOGMEL_CM16, want_absmax=True, want_lo=False)
+    assert hi.lo is None and torch.equal(hi.data, full.data) and torch.equal(hi.absmax, full.absmax)
+    with pytest.raises(_lib.MstError, match="HIGH parts"):
+        hi.to_reference()
+    m = _build(cases.CFG_DEFAULT, "f16")
+    feats = torch.randn(2, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    with torch.no_grad():
+        e_hi = m.hip_encoder().forward(hi, feats)
+        e_full = m.hip_encoder().forward(full, feats)
+    assert torch.equal(e_hi, e_full)
+    with pytest.raises(_lib.MstError, match="low parts"):
+        _build(cases.CFG_DEFAULT, "f16x3-all").hip_encoder().forward(hi, feats)
+    seen = []
+    orig = plan.__class__.forward_stems
+
+    def spy(self, *a, **k):
+        seen.append(k.get("want_lo", True))
+        return orig(self, *a, **k)
+    plan.__class__.forward_stems = spy
+    try:
+        with torch.no_grad():
+            m(d, feats)
+        mt = _build(cases.CFG_DEFAULT).train()
+        mt.train_backend, mt.train_precision = "hip-strict", "f16"
+        mt(d, feats).sum().backward()
+        mt.train_precision = "f16x3"
+        mt(d, feats).sum().backward()
+    finally:
+        plan.__class__.forward_stems = orig
+    assert seen == [False, False, True], seen
