@@ -214,7 +214,9 @@ def main():
     model = model.to(dev).eval()
     model.conv1_precision = a.precision
     fe = MixingFeatureExtractor(sr, n_fft, hop, n_mels)
-    crit = InfoNCELoss(0.1, gather=world > 1)
+    # the reference's "no positive pairs" guard is evaluated one call late from a pinned word (check="deferred"): the same
+    # RuntimeError, without a device -> host read that would leave the GPU idle between steps (mst_amd/loss.py)
+    crit = InfoNCELoss(0.1, gather=world > 1, check="deferred")
     augm = AudioAugmenter(sr, 9.0, 0.5)
     torch.manual_seed(1234 + rank)
 
@@ -294,7 +296,7 @@ def main():
             opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
         except (TypeError, RuntimeError):
             opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
-        crit_t = InfoNCELoss(0.1, gather=world > 1)
+        crit_t = InfoNCELoss(0.1, gather=world > 1, check="deferred")
         amp = a.train_precision == "amp"
         scaler = torch.amp.GradScaler("cuda") if amp else None
         reducer = None
@@ -329,6 +331,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(a.steps):
             loss = train_step()
+        crit_t.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -364,6 +367,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step(True)
+    crit.finish()   # the last step's guard (inside the timed region: a device -> host read of one word)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -482,7 +486,8 @@ def main():
                        "clips_per_gpu": B, "clip_samples": T, "n_fft": n_fft, "hop": hop, "n_mels": n_mels,
                        "encoder_backend": backend, "conv1_precision": a.precision,
                        "logmel_layout": {0: "reference (B,8,M,F)", 1: "channel-minor [B][F][M][8] fp32 (encoder-internal)",
-                                         2: "channel-minor float16 hi/lo planes (encoder-internal)"}[layout_now()], "parallelism": f"clip-sharded x{world}", "loss": float(loss)},
+                                         2: "channel-minor float16 hi/lo planes (encoder-internal)"}[layout_now()], "parallelism": f"clip-sharded x{world}", "loss": float(loss),
+                       "loss_guard": "the reference's no-positive-pairs RuntimeError is evaluated one call late from a pinned word (InfoNCELoss check='deferred'): no per-step device->host read"},
             "roofline": roof,
         }
         out["alt"] = alt

@@ -68,7 +68,7 @@ def main(argv=None):
     model.train_precision = a.train_precision
     model.small_nets_backend = a.small_nets
     deferred = torch.stack([deferred_features(64)] * (2 * a.batch_size)).to(dev)   # what the Dataset's feature slot carries
-    crit = InfoNCELoss(0.1)
+    crit = InfoNCELoss(0.1)   # (check="deferred" would drop the per-step read-back of the guard; this loop reads loss.item() anyway)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr)
     stager = ingest.DeviceStager((2 * a.batch_size, 8, ds.clip_samples), torch.int16, dev)
     losses, step = [], 0

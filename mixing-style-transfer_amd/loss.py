@@ -114,12 +114,34 @@ def info_nce_rows_hip(all_emb, all_labels, row0, rows, temperature):
 
 
 class InfoNCELoss(nn.Module):
-    """Drop-in for reference InfoNCELoss(temperature)(embeddings (N, D), song_labels (N,)) -> scalar."""
+    """Drop-in for reference InfoNCELoss(temperature)(embeddings (N, D), song_labels (N,)) -> scalar.
 
-    def __init__(self, temperature=0.1, gather=False):
+    `check`: how the reference's "No positive pairs found in batch!" guard (src/loss.py) is evaluated on the GPU path.
+      "sync" (default)  -- as the reference: the count of anchors with a positive is read back and the RuntimeError raised before
+                           the call returns.  One device -> host read per call: the host waits for the whole step and the GPU
+                           idles for the launch latency of the next step's first kernels (~0.2 ms per step on this chip).
+      "deferred"        -- the count goes to a pinned host word with an asynchronous copy; it is examined at the NEXT call (and
+                           by `finish()`), by which time the next step's kernels are queued: the same RuntimeError, one call
+                           later, no idle GPU.  The step without positives itself returns a zero loss with zero gradients
+                           (sum 0 / max(count, 1)), so nothing is corrupted before the error surfaces."""
+
+    def __init__(self, temperature=0.1, gather=False, check="sync"):
         super().__init__()
+        if check not in ("sync", "deferred"):
+            raise ValueError("check must be 'sync' or 'deferred'")
         self.temperature = temperature
         self.gather = gather
+        self.check = check
+        self._pending = None   # (pinned count, event, message) of the previous call
+
+    def finish(self):
+        """Deferred mode: examine the last call's guard now (waits for that call's kernels); raises the RuntimeError it owes."""
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            flag, ev, msg = pend
+            ev.synchronize()
+            if flag.item() == 0:
+                raise RuntimeError(msg)
 
     def forward(self, embeddings, song_labels):
         if self.gather:
@@ -132,6 +154,17 @@ class InfoNCELoss(nn.Module):
             embeddings, song_labels = all_e, all_l
         rows_fn = info_nce_rows_hip if embeddings.is_cuda else info_nce_rows
         s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
+        if self.check == "deferred" and embeddings.is_cuda:
+            self.finish()   # the PREVIOUS call's guard (its kernels are long done or at most one step behind)
+            bufs = self.__dict__.setdefault("_flags", [torch.zeros(1).pin_memory(), torch.zeros(1).pin_memory()])
+            self._turn = 1 - getattr(self, "_turn", 0)
+            flag = bufs[self._turn]
+            flag.copy_(c.detach().reshape(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (flag, ev, f"No positive pairs found in batch! Batch size: {embeddings.shape[0]}, "
+                                       "This likely means each song only appears once in the batch.")
+            return s / torch.clamp(c, min=1.0)
         if c.item() == 0:
             raise RuntimeError(
                 f"No positive pairs found in batch! Batch size: {embeddings.shape[0]}, "

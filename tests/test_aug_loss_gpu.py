@@ -170,3 +170,27 @@ def test_packed_strided_in_place_variant_equals_augment_stems():
         for b in (1, 2, 4, 5):
             assert torch.equal(y[b], x[b])
         assert not torch.equal(y[0], x[0])
+
+
+def test_infonce_deferred_guard_raises_one_call_later_and_corrupts_nothing():
+    """`InfoNCELoss(check="deferred")`: the reference's "No positive pairs found in batch!" RuntimeError (src/loss.py) without a
+    device -> host read per call -- a batch without positives gives a ZERO loss with zero gradients, and the error is raised by the
+    next call (or `finish()`); batches with positives give exactly the "sync" value."""
+    from mst_amd.loss import InfoNCELoss
+    g = torch.Generator().manual_seed(2)
+    e = torch.randn(8, 64, generator=g).cuda().requires_grad_(True)
+    good, bad = (torch.arange(8) // 2).cuda(), torch.arange(8).cuda()
+    sync, lazy = InfoNCELoss(0.1), InfoNCELoss(0.1, check="deferred")
+    assert torch.equal(sync(e, good), lazy(e, good))
+    with pytest.raises(RuntimeError, match="No positive pairs"):
+        sync(e, bad)
+    loss = lazy(e, bad)                        # no error yet
+    loss.backward()
+    assert loss.item() == 0.0 and float(e.grad.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="No positive pairs"):
+        lazy(e, good)                          # the previous call's guard
+    assert torch.equal(lazy(e, good), sync(e, good))   # the error was consumed; the criterion works on
+    lazy(e, bad)
+    with pytest.raises(RuntimeError, match="No positive pairs"):
+        lazy.finish()
+    lazy.finish()                              # nothing pending
