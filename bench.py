@@ -25,6 +25,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
+MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; the 5 PF headline is 2:1 sparsity)
 
 
 def parse():
@@ -34,7 +35,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--triplets", type=int, default=24, help="triplets per GPU per step (3 clips each)")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--encoder", choices=["auto", "hip", "torch"], default="auto")
+    ap.add_argument("--encoder", choices=["hip", "torch"], default="hip",
+                    help="hip (default, configs[2]): stage B on libmst.so's hand-written kernels; a missing / refusing HIP encoder is "
+                         "an error, never a library fallback.  torch: BASELINE configs[1], stage B on PyTorch-ROCm (explicit opt-in)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the post-timing correctness check of the timed workload (config.verified)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "f16x3", "f16x3-all", "f16"], default="fp32",
                     help="conv1 arithmetic: exact fp32 MFMA (default) or opt-in 3-term split-precision f16 MFMA")
@@ -67,39 +72,76 @@ def parse():
     return ap.parse_args()
 
 
-def hip_encoder_available():
-    from mst_amd import _lib
-    import ctypes as C
-    h = C.c_void_p()
-    rc = _lib.lib().mst_encoder_create(C.byref(h), None, None)
-    return b"not implemented" not in (_lib.lib().mst_last_error() or b"")
-
-
-def cpu_baseline(model_sd, cfg, T, budget_s=15.0):
-    """CPU oracle (the parity-pinned restatement of the reference path) on the host cores, bounded sample."""
+def cpu_baseline(model_sd, x, cfg, budget_s=15.0):
+    """CPU oracle (the parity-pinned restatement of the reference path) on the host cores, bounded sample.
+    x: (3, 8, T) fp32 on the CPU -- three clips of the TIMED batch (first, middle, last), so that the embeddings this leg
+    computes anyway double as the checker of the timed workload (returned second; see `verify`)."""
     from oracle import encoder as oenc
     from oracle import features as ofeat
-    from mst_amd.synth import synth_batch
     # the GPU box gives a 1-GPU job a share of 16 host cores; os.cpu_count() reports the whole machine
     ncpu = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(ncpu)
     sd = {k: v.detach().cpu() for k, v in model_sd.items()}
-    B = 3  # one triplet per iteration
-    x = synth_batch(B, T)
+    B, T = x.shape[0], x.shape[-1]
+    geo = (cfg["sr"], cfg["n_fft"], cfg["hop"], cfg["n_mels"])
     clips, t0 = 0, time.perf_counter()
     with torch.no_grad():
-        oenc.encoder_forward(sd, x[:1], ofeat.extract_all_features(x[:1]))  # warm-up (thread pools, fft plans)
+        oenc.encoder_forward(sd, x[:1], ofeat.extract_all_features(x[:1], *geo), *geo, cfg["split"], cfg["overlap"])  # warm-up (thread pools, fft plans)
         t0 = time.perf_counter()
         while True:
-            f = ofeat.extract_all_features(x)          # reference: computed in the Dataset worker
-            oenc.encoder_forward(sd, x, f)             # reference: MixingStyleEncoder.forward (mel again + CNN)
+            f = ofeat.extract_all_features(x, *geo)                                  # reference: computed in the Dataset worker
+            emb = oenc.encoder_forward(sd, x, f, *geo, cfg["split"], cfg["overlap"])  # reference: MixingStyleEncoder.forward (mel again + CNN)
             clips += B
             el = time.perf_counter() - t0
             if el > budget_s or clips >= 150:
                 break
     return {"value": round(clips / 3.0 / el, 4), "unit": "triplets/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{clips} clips ({clips // 3} triplets) of {T / 44100:.0f} s, oracle/ "
-            f"features+mel+encoder fwd, torch-CPU fp32, {el:.1f} s wall"}
+            "kind": "port", "sample": f"{clips} clips ({clips // 3} triplets) of {T / cfg['sr']:.0f} s (clips first / middle / last of "
+            f"the timed batch), oracle/ features+mel+encoder fwd, torch-CPU fp32, {el:.1f} s wall"}, emb
+
+
+def verify(model, fe, lay_fn, backend, last):
+    """Post-timing correctness check of the workload that was just TIMED, at its own size (the launch shapes of the 72 x 10 s
+    batch take index paths no small parity case does): every clip of the last timed step's batch is run again alone (B = 1)
+    through the same stage-A + encoder path and must reproduce its embedding BIT FOR BIT (HIP encoder; the library backend of
+    configs[1] is held to 1e-4 of the embedding's maximum instead).  Returns the dict that becomes config.verified; `ok` False
+    makes the bench exit non-zero.  `verify_oracle` adds the comparison with the CPU oracle."""
+    from mst_amd import _lib as mlib
+    emb, stems = last["emb"], last["stems"]
+    B = emb.shape[0]
+    out = {"clips": 0, "max_rel": None, "ok": True}
+    if stems is None:   # --ingest: the staged batch is gone by now
+        return out
+    bad, worst = 0, 0.0
+    with torch.no_grad():
+        for c in range(B):
+            one = {k: v[c:c + 1] for k, v in stems.items()}
+            lay = lay_fn()
+            f1, lm1 = fe.features_and_logmel(one, lay, lay == mlib.LOGMEL_CM16)
+            e1 = model.hip_encoder().forward(lm1, f1) if backend == "hip" else model.forward_from_logmel(lm1, f1)
+            if not torch.equal(e1[0], emb[c]):
+                bad += 1
+                worst = max(worst, float((e1[0] - emb[c]).abs().max() / emb[c].abs().max().clamp(min=1e-30)))
+    out["batch_independence"] = {"clips": B, "bit_equal": B - bad, "worst_rel_to_max": worst}
+    out["clips"] = B
+    out["ok"] = bad == 0 if backend == "hip" else worst <= 1e-4
+    return out
+
+
+def verify_oracle(out, emb, oracle_clips, oracle_emb, precision):
+    """The embeddings of `oracle_clips` against the CPU oracle's (computed by the cpu_baseline leg on the same clips of the timed
+    batch): every element within 1e-4 of max(|ref|, 1e-2 max|ref|) -- the element-wise bar of tests/test_encoder_gpu.py (plain f16
+    operands, an opt-in mode outside the parity bar: 1e-3)."""
+    tol = 1e-3 if precision == "f16" else 1e-4
+    got = emb[oracle_clips].detach().cpu().double()
+    ref = oracle_emb.double()
+    rel = (got - ref).abs() / torch.maximum(ref.abs(), 1e-2 * ref.abs().amax(dim=1, keepdim=True))
+    out["oracle"] = {"clips": list(oracle_clips), "max_rel": float(rel.max()), "tol": tol,
+                     "beyond_tol": int((rel > tol).sum()), "elements": rel.numel(),
+                     "normwise": float(((got - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max())}
+    out["max_rel"] = out["oracle"]["max_rel"]
+    out["ok"] = out["ok"] and out["oracle"]["beyond_tol"] == 0
+    return out
 
 
 def launch_ranks(a):
@@ -202,7 +244,7 @@ def main():
         n_mels = 256
     T = int(a.seconds * sr)
     B = 3 * a.triplets
-    backend = a.encoder if a.encoder != "auto" else ("hip" if hip_encoder_available() else "torch")
+    backend = a.encoder   # "hip" unless the caller asks for configs[1]: a HIP encoder that cannot run raises (rc != 0), nothing falls back
 
     torch.manual_seed(42)
     model = MixingStyleEncoder(sr, n_fft, hop, n_mels, split, overlap, 8, embed, feature_dim=64, encoder_backend=backend)
@@ -218,6 +260,7 @@ def main():
     # RuntimeError, without a device -> host read that would leave the GPU idle between steps (mst_amd/loss.py)
     crit = InfoNCELoss(0.1, gather=world > 1, check="deferred")
     augm = AudioAugmenter(sr, 9.0, 0.5)
+    last = {}   # the last step's inputs and embeddings (for the post-timing check)
     torch.manual_seed(1234 + rank)
 
     x = synth_batch(B, T, sr, device=dev, first_clip=rank * B)   # resident in HBM before timing
@@ -250,12 +293,13 @@ def main():
         return lay if fe.plan().supports_layout(lay) else mlib.LOGMEL_REF
 
     marks, pending = [], []
-    pool = [[ev() for _ in range(9)] for _ in range(a.steps)]   # events are created outside the timed region
+    pool = [[ev() for _ in range(12)] for _ in range(a.steps)]   # events are created outside the timed region
 
     def step(timed):
         with torch.no_grad():
             evs = pool[len(marks)] if timed else None
             e0, e1, e2 = evs[:3] if timed else (None, None, None)
+            crit.gather_events = (evs[9], evs[10]) if timed and world > 1 else None
             lay = layout_now()
             if timed:
                 e0.record()
@@ -263,6 +307,7 @@ def main():
                 xa[2::3].copy_(x[2::3])   # the reference's `.clone()` (src/mixing_utils.py:386) ...
                 augm.augment_packed_(xa[2::3], decisions=pending.pop() if pending else None)   # ... augmented where it stands
                 feats, logmel = fe.features_and_logmel(stems_aug, lay, lay == mlib.LOGMEL_CM16)
+                last["stems"] = stems_aug
             elif stager is not None:
                 fut = state["fut"]
                 xin = fut.get()
@@ -270,26 +315,32 @@ def main():
                 state["fut"] = stager.submit(host_batches[state["k"] % 2])   # next batch's H2D overlaps this step
                 feats, logmel = fe.features_and_logmel(ingest.stems_views(xin), lay, lay == mlib.LOGMEL_CM16)
                 stager.release(fut)
+                last["stems"] = None
             else:
                 feats, logmel = fe.features_and_logmel(stems, lay, lay == mlib.LOGMEL_CM16)
+                last["stems"] = stems
             if timed:
                 e1.record()
             if backend == "hip":
-                kev = evs[3:] if timed else None
+                kev = evs[3:9] if timed else None
                 emb = model.hip_encoder().forward(logmel, feats, events=kev)
             else:
                 kev = None
                 emb = model.forward_from_logmel(logmel, feats)
             if timed:
                 e2.record()
-                marks.append((e0, e1, e2, kev))
             if a.aug:   # host RNG work for the NEXT step overlaps this step's kernels (a data-loader worker's job)
                 pending.append(augm.draw_decisions(B // 3))
-            return crit(emb, labels)
+            loss = crit(emb, labels)
+            if timed:
+                evs[11].record()
+                marks.append((e0, e1, e2, kev, evs[11], crit.gather_events))
+            last["emb"] = emb
+            return loss
 
     if a.train:   # training step: same data, same metric unit; reported with its own workload string
         model.train()
-        model.train_backend = "hip-strict" if a.train_backend == "hip" else a.train_backend   # never time a silent library fallback
+        model.train_backend = a.train_backend   # "hip" raises when the hand-written trunk cannot take the call: no library fallback is ever timed
         model.train_precision = {"fp32": "fp32", "f16": "f16", "f16x3": "f16x3", "amp": "auto"}[a.train_precision]
         model.sync_bn = bool(a.sync_bn)
         try:   # the multi-tensor ("fused") AdamW of PyTorch: the same update in a handful of launches instead of ~25
@@ -372,47 +423,115 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+
+    # per-rank figures for the N > 1 line (why the scaling factor is what it is): every rank's own wall time for the K steps
+    per_rank_ms = None
+    if world > 1:
+        mine = torch.tensor([el / a.steps * 1e3], device=dev, dtype=torch.float64)
+        allr = torch.empty(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank_ms = [round(v, 4) for v in allr.tolist()]
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = t.item()
 
+    # post-timing check of the timed workload itself (outside the timed region): batch independence on every rank; the oracle
+    # comparison rides on the cpu_baseline leg (rank 0, N = 1), see verify()
+    main_emb = last["emb"].clone()
+    oracle_clips = [0, (B // 2) // 3 * 3, B - 1] if B >= 3 else list(range(B))   # first, a middle anchor, the last (a negative under --aug)
+    verified, base, ox = None, None, None
+    if not a.no_verify:
+        if rank == 0 and world == 1 and not a.no_cpu_baseline and last["stems"] is not None:
+            ox = torch.cat([torch.cat([last["stems"][s][c:c + 1] for s in ("vocals", "bass", "drums", "other")], 1)
+                            for c in oracle_clips], 0).float().cpu()
+        verified = verify(model, fe, layout_now, backend, last)
+        okf = torch.tensor([1.0 if verified["ok"] else 0.0], device=dev)
+        if world > 1:
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        verified["ok_all_ranks"] = bool(okf.item() == 1.0)
+
     # opt-in precision modes, measured after (outside) the contract's timed region; the headline stays exact fp32
     alt = None
+    main_marks = len(marks)
     if backend == "hip" and a.precision == "fp32" and not a.aug and a.ingest == "resident" and a.config == "default":
-        notes = {"f16x3-all": "conv1+conv2 on f16 MFMA with 3-term split precision, fp32 accumulate; embeddings within 1e-6 "
-                              "(rel. to max) of the exact-fp32 kernels, same 1e-4 parity tests",
+        notes = {"f16x3-all": "conv1+conv2 on f16 MFMA with 3-term split precision, fp32 accumulate; same 1e-4 parity tests as the exact-fp32 kernels",
                  "f16": "conv1+conv2 with plain f16 operands, fp32 accumulate (the reference's --use_amp conv arithmetic); "
-                        "embeddings ~2e-4 of max from fp32: NOT within the 1e-4 parity bar, shown for headroom only"}
+                        "NOT within the 1e-4 parity bar, shown for headroom only"}
         alt = []
         n_alt = max(5, a.steps // 2)
-        main_marks = len(marks)
         for mode, note in notes.items():
             model.conv1_precision = mode
             try:
                 for _ in range(3):
                     step(False)
+                pool.extend([[ev() for _ in range(12)] for _ in range(n_alt)])
+                m0 = len(marks)
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
                 ta = time.perf_counter()
                 for _ in range(n_alt):
-                    step(False)
+                    step(True)
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
                 tb = torch.tensor([time.perf_counter() - ta], device=dev, dtype=torch.float64)
                 if world > 1:
                     dist.all_reduce(tb, op=dist.ReduceOp.MAX)
-                alt.append({"mode": f"{mode}: {note}", "value": round(world * a.triplets * n_alt / tb.item(), 3),
-                            "unit": "triplets/s", "ms_per_step": round(tb.item() / n_alt * 1e3, 4), "steps": n_alt})
-            except Exception as ex:  # e.g. activations too close to the f16 range: the mode refuses to run
+                mm = marks[m0:]
+                k_ms = [sum(m[3][i].elapsed_time(m[3][i + 1]) for m in mm) / len(mm) for i in range(5)]
+                a_ms = sum(m[0].elapsed_time(m[1]) for m in mm) / len(mm)
+                terms = 3 if mode.startswith("f16x3") else 1
+                ns_, nfr = model.audio_encoder.n_subbands, 1 + T // hop
+                fl1 = B * ns_ * 2.0 * 32 * 392 * split * nfr
+                fl2 = B * ns_ * 2.0 * 64 * 1568 * 8 * (nfr // 5)
+                d = (last["emb"] - main_emb).abs()
+                row = {"mode": f"{mode}: {note}", "value": round(world * a.triplets * n_alt / tb.item(), 3),
+                       "unit": "triplets/s", "ms_per_step": round(tb.item() / n_alt * 1e3, 4), "steps": n_alt,
+                       "kernels_ms": {"stage_a": round(a_ms, 4), "film_mlp": round(k_ms[0], 4), "conv1": round(k_ms[1], 4),
+                                      "conv2": round(k_ms[2], 4), "attn_scores": round(k_ms[3], 4), "attn_pool_proj": round(k_ms[4], 4)},
+                       # executed MFMA flops (each product as `terms` f16 MFMAs) against the dense f16 peak; the chip holds ~1.8-1.9 GHz
+                       # under f16 MFMA load, i.e. ~1.9 PFLOP/s is what a perfect kernel would reach
+                       "roofline": {"bound": "mfma", "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "mfma_terms": terms,
+                                    "conv1_achieved_executed": round(terms * fl1 / (k_ms[1] * 1e-3) / 1e12, 1),
+                                    "conv1_frac": round(terms * fl1 / (k_ms[1] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
+                                    "conv2_achieved_executed": round(terms * fl2 / (k_ms[2] * 1e-3) / 1e12, 1),
+                                    "conv2_frac": round(terms * fl2 / (k_ms[2] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)},
+                       "embedding_error_vs_fp32_kernels": {
+                           "normwise": float((d.amax(dim=1) / main_emb.abs().amax(dim=1)).max()),
+                           "max_rel_elementwise": float((d / torch.maximum(main_emb.abs(), 1e-2 * main_emb.abs().amax(dim=1, keepdim=True))).max())}}
+                if not a.no_verify:
+                    v = verify(model, fe, layout_now, backend, last)
+                    row["verified"] = v
+                    if not v["ok"]:
+                        verified["ok"] = False
+                alt.append(row)
+            except Exception as ex:  # a mode that refuses to run is reported, not hidden
                 alt.append({"mode": mode, "error": str(ex)[:200]})
         model.conv1_precision = a.precision
         del marks[main_marks:]
 
     msA = sum(m[0].elapsed_time(m[1]) for m in marks) / len(marks)
     msB = sum(m[1].elapsed_time(m[2]) for m in marks) / len(marks)
+    # per-step periods on the GPU's own clock (step i's first event to step i+1's; the last step: to its loss event), for the
+    # median SURVEY 8(d) asks for next to the mean over the wall clock
+    periods = sorted([marks[i][0].elapsed_time(marks[i + 1][0]) for i in range(len(marks) - 1)] + [marks[-1][0].elapsed_time(marks[-1][4])])
+    ms_median = periods[len(periods) // 2] if len(periods) % 2 else 0.5 * (periods[len(periods) // 2 - 1] + periods[len(periods) // 2])
+    multi = None
+    if world > 1:   # what explains the N-GPU scaling factor: each rank's own kernels (stage A + B) and the exchange's share
+        own = msA + msB
+        gat = sum(m[5][0].elapsed_time(m[5][1]) for m in marks) / len(marks)
+        mine = torch.tensor([own, gat, sum(m[2].elapsed_time(m[4]) for m in marks) / len(marks)], device=dev, dtype=torch.float64)
+        allr = torch.empty(world * 3, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        allr = allr.view(world, 3).cpu()
+        multi = {"per_rank_ms_per_step_wall": per_rank_ms,
+                 "per_rank_own_kernels_ms": {"min": round(float(allr[:, 0].min()), 4), "max": round(float(allr[:, 0].max()), 4)},
+                 "all_gather_ms": {"min": round(float(allr[:, 1].min()), 4), "max": round(float(allr[:, 1].max()), 4),
+                                   "note": "events around the packed embedding + label all-gather on the compute stream: includes waiting for the slowest rank's embeddings"},
+                 "exchange_plus_loss_ms": {"min": round(float(allr[:, 2].min()), 4), "max": round(float(allr[:, 2].max()), 4)},
+                 "all_gather_share_of_step": round(float(allr[:, 1].max()) / (el / a.steps * 1e3), 4)}
     if rank == 0:
         n_frames = 1 + T // hop
         bytes_a = B * (8 * T * 4 + 8 * n_mels * n_frames * 4 + 64 * 4)      # 21,169,664 B/clip
@@ -471,6 +590,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 4),
+            "ms_per_step_median": round(ms_median, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -491,11 +611,22 @@ def main():
             "roofline": roof,
         }
         out["alt"] = alt
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model.state_dict(), None, T)
+            cfg = dict(sr=sr, n_fft=n_fft, hop=hop, n_mels=n_mels, split=split, overlap=overlap)
+            if ox is None:   # no stems to check against (--ingest / --no-verify): the baseline runs on the synthetic clips themselves
+                ox = x[oracle_clips].float().cpu()
+            out["cpu_baseline"], oemb = cpu_baseline(model.state_dict(), ox, cfg)
+            if verified is not None and last["stems"] is not None:
+                verify_oracle(verified, main_emb, oracle_clips, oemb, a.precision)
+        out["config"]["verified"] = verified if verified is not None else "skipped (--no-verify)"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if verified is not None and not (verified["ok"] and verified.get("ok_all_ranks", True)):
+        print(f"bench.py: the timed workload FAILED its correctness check: {json.dumps(verified)}", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

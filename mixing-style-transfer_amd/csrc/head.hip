@@ -375,6 +375,13 @@ HeadWork head_work(int B, int C, int T, int A, int E) {
 }
 }  // namespace
 
+// head_pool_kernel / head_ds_kernel / head_da_kernel keep T (4 T for head_da_kernel) floats in dynamic LDS: bounded here, in BOTH
+// entry points, so that an over-long clip is refused before any kernel of the pass has run (2048 pooled frames = 4 minutes of audio)
+constexpr int kHeadMaxFrames = 2048;
+static bool head_dims_ok(int C, int T, int A, int E) {
+  return C >= 1 && C <= 3072 && T >= 1 && T <= kHeadMaxFrames && A >= 1 && A <= 256 && E >= 1;
+}
+
 extern "C" {
 
 int mst_dropout_mask(float p, uint64_t seed, long long n, unsigned char* keep, void* stream) {
@@ -401,7 +408,7 @@ int mst_head_forward_train(const mst_head_dims* dm, const mst_head_weights* w, c
   MST_REQUIRE(dm && w && pool_in && emb && save && B > 0, "mst_head_forward_train: NULL / bad argument");
   MST_REQUIRE(w->att0_w && w->att0_b && w->att2_w && w->att2_b && w->proj_w && w->proj_b, "mst_head_forward_train: NULL weight");
   const int C = dm->channels, T = dm->frames, A = dm->attn_hidden, E = dm->embed_dim;
-  MST_REQUIRE(C >= 1 && T >= 1 && A >= 1 && A <= 256 && E >= 1 && C <= 3072, "mst_head_forward_train: dims out of range (C=%d T=%d A=%d E=%d)", C, T, A, E);
+  MST_REQUIRE(head_dims_ok(C, T, A, E), "mst_head_forward_train: dims out of range (C=%d T=%d A=%d E=%d; limits C <= 3072, T <= %d, A <= 256)", C, T, A, E, kHeadMaxFrames);
   MST_REQUIRE(drop_in_p >= 0.f && drop_in_p < 1.f && drop_out_p >= 0.f && drop_out_p < 1.f, "mst_head_forward_train: dropout p must be in [0, 1)");
   const HeadSave S = head_save(B, C, T, A, E, drop_in_p > 0.f);
   if (save_bytes < S.total * sizeof(float)) return mst::fail(MST_ENOMEM, "mst_head_forward_train: save buffer %zu B < %zu B", save_bytes, S.total * sizeof(float));
@@ -435,7 +442,8 @@ int mst_head_backward(const mst_head_dims* dm, const mst_head_weights* w, const 
   MST_REQUIRE(dm && w && pool_in && demb && save && g && dpool_in && workspace && B > 0, "mst_head_backward: NULL / bad argument");
   MST_REQUIRE(g->att0_w && g->att0_b && g->att2_w && g->att2_b && g->proj_w && g->proj_b, "mst_head_backward: NULL gradient pointer");
   const int C = dm->channels, T = dm->frames, A = dm->attn_hidden, E = dm->embed_dim;
-  MST_REQUIRE(A <= 256, "mst_head_backward: attn_hidden %d > 256", A);
+  MST_REQUIRE(head_dims_ok(C, T, A, E), "mst_head_backward: dims out of range (C=%d T=%d A=%d E=%d; limits C <= 3072, T <= %d, A <= 256)", C, T, A, E, kHeadMaxFrames);
+  MST_REQUIRE(drop_in_p >= 0.f && drop_in_p < 1.f && drop_out_p >= 0.f && drop_out_p < 1.f, "mst_head_backward: dropout p must be in [0, 1)");
   const HeadSave S = head_save(B, C, T, A, E, drop_in_p > 0.f);
   const HeadWork Wk = head_work(B, C, T, A, E);
   if (workspace_bytes < Wk.total * sizeof(float)) return mst::fail(MST_ENOMEM, "mst_head_backward: workspace %zu B < %zu B", workspace_bytes, Wk.total * sizeof(float));

@@ -123,7 +123,13 @@ class InfoNCELoss(nn.Module):
       "deferred"        -- the count goes to a pinned host word with an asynchronous copy; it is examined at the NEXT call (and
                            by `finish()`), by which time the next step's kernels are queued: the same RuntimeError, one call
                            later, no idle GPU.  The step without positives itself returns a zero loss with zero gradients
-                           (sum 0 / max(count, 1)), so nothing is corrupted before the error surfaces."""
+                           (sum 0 / max(count, 1)).  That step is NOT a no-op for the trainer's state: `optimizer.step()` on
+                           zero gradients still applies weight decay and moves Adam's moments, and a training forward has
+                           already updated the BatchNorm running statistics -- the model is one decay / momentum step past
+                           the last good batch when the error surfaces.  `finish()` is therefore MANDATORY after the last
+                           step of a loop and before every checkpoint (otherwise the last call's error is never raised);
+                           the owed error of the previous call is raised at the top of the next call, before any of that
+                           call's kernels are queued."""
 
     def __init__(self, temperature=0.1, gather=False, check="sync"):
         super().__init__()
@@ -133,6 +139,7 @@ class InfoNCELoss(nn.Module):
         self.gather = gather
         self.check = check
         self._pending = None   # (pinned count, event, message) of the previous call
+        self.gather_events = None   # optional (start, end) torch.cuda.Event pair recorded around the all-gather (bench.py, N > 1)
 
     def finish(self):
         """Deferred mode: examine the last call's guard now (waits for that call's kernels); raises the RuntimeError it owes."""
@@ -144,18 +151,23 @@ class InfoNCELoss(nn.Module):
                 raise RuntimeError(msg)
 
     def forward(self, embeddings, song_labels):
+        if self.check == "deferred" and embeddings.is_cuda:
+            self.finish()   # the PREVIOUS call's guard, before this call queues anything (its kernels are at most one step behind)
         if self.gather:
             # sharded batch: one packed all-gather, then EVERY rank evaluates the whole loss on the gathered batch
             # (N^2 D flops: negligible next to the encoder).  No all-reduce in the forward, none in the backward:
             # the local slice of d loss / d all_embeddings is already complete, and the value is identical on all
             # ranks.  Parameter gradients must be SUMMED over ranks (each rank holds the part that flows through
             # its own clips).
+            if self.gather_events is not None:
+                self.gather_events[0].record()
             all_e, all_l, _ = gather_embeddings(embeddings, song_labels, reduce_grad=False)
+            if self.gather_events is not None:
+                self.gather_events[1].record()
             embeddings, song_labels = all_e, all_l
         rows_fn = info_nce_rows_hip if embeddings.is_cuda else info_nce_rows
         s, c = rows_fn(embeddings, song_labels, 0, embeddings.shape[0], self.temperature)
         if self.check == "deferred" and embeddings.is_cuda:
-            self.finish()   # the PREVIOUS call's guard (its kernels are long done or at most one step behind)
             bufs = self.__dict__.setdefault("_flags", [torch.zeros(1).pin_memory(), torch.zeros(1).pin_memory()])
             self._turn = 1 - getattr(self, "_turn", 0)
             flag = bufs[self._turn]

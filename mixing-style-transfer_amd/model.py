@@ -9,8 +9,9 @@ Forward paths
   * training with autograd (`model.train()` and grad enabled, `train_backend = "hip"`, the default): stage A in HIP (the
     waveform needs no gradient); the conv trunk -- train-mode BatchNorm forward, Dropout, and the whole backward (pool /
     ReLU / FiLM / BatchNorm, conv2 input gradient, both conv weight gradients) -- in hand-written HIP kernels behind one
-    autograd Function (`_HipTrunk`); the FiLM MLP and the attention head (0.4 % of the flops) stay torch modules.
-    `train_backend = "torch"` runs the whole encoder on PyTorch-ROCm autograd (the path the gradients are tested against).
+    autograd Function (`_HipTrunk`); pooling head and FiLM MLP in csrc/head.hip.  A call the hand-written trunk cannot take
+    RAISES (no silent library path); the library paths are explicit opt-ins: `train_backend = "torch"` runs the whole encoder on
+    PyTorch-ROCm autograd (the path the gradients are tested against), `"hip-or-torch"` warns once per reason and falls back.
 """
 import ctypes as C
 
@@ -602,6 +603,7 @@ class _HipTrunk(torch.autograd.Function):
                                  want_pool1=not enc.train_f16, want_film=False, want_bn=want_bn)
         mask = t.get("drop1_mask")
         ctx.enc, ctx.drop_p, ctx.dims, ctx.sync, ctx.reducer = enc, drop_p, (B, Fr), sync, reducer
+        ctx.trunk_params = params   # family-major (MixingStyleEncoder._TRUNK_FAMILIES): the reducer maps stacked gradients to their owners
         ctx.gen, ctx.mode = enc._gen_counter, enc.train_mode
         # (the workspace rides with the saved tensors: autograd releases it with them after a backward that does not retain the graph)
         if isinstance(logmel, LogMel):   # stage A's float16 planes: kept for conv1's weight gradient as they are
@@ -651,7 +653,7 @@ class _HipTrunk(torch.autograd.Function):
         dbn2w, dbn2b = dbn2[..., 0], dbn2[..., 1]   # contiguous planes (no copies)
         reducer = ctx.reducer
         if reducer is not None:   # data parallel: the conv2-side gradients are final -- their all-reduce runs behind the rest of
-            reducer.reduce_stacked("conv2", [gw2, gb2, dbn2w, dbn2b])   # this backward (dist.GradientReducer)
+            reducer.reduce_stacked("conv2", [gw2, gb2, dbn2w, dbn2b], [ctx.trunk_params[f * ns:(f + 1) * ns] for f in (4, 5, 6, 7)])   # this backward (dist.GradientReducer)
         dp1 = enc.conv2_dgrad(dy2, B, Fr, mask, ctx.drop_p)   # input gradient (Dropout mask fused)
         mark("conv2_dgrad")
         _, dbn1 = enc.backward_apply(1, dp1, dfilm, B, Fr, inplace=True, sync=sync)
@@ -664,7 +666,7 @@ class _HipTrunk(torch.autograd.Function):
             _HipTrunk.last_timing = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks[:-1], marks[1:])}
         dbn1w, dbn1b = dbn1[..., 0], dbn1[..., 1]
         if reducer is not None:
-            reducer.reduce_stacked("conv1", [gw1, gb1, dbn1w, dbn1b])
+            reducer.reduce_stacked("conv1", [gw1, gb1, dbn1w, dbn1b], [ctx.trunk_params[f * ns:(f + 1) * ns] for f in (0, 1, 2, 3)])
         fams = (gw1, gb1, dbn1w, dbn1b, gw2, gb2, dbn2w, dbn2b)
         return (None, None, dfilm, None, None, None, None, None) + tuple(g[i] for g in fams for i in range(ns))
 
@@ -769,9 +771,11 @@ class MixingStyleEncoder(nn.Module):
         self._hip = None
         self._hip_version = None
         self._hip_train = None
-        # training (grad enabled, model.train()): "hip" = conv trunk forward + pool/ReLU/FiLM/BatchNorm backward in libmst.so
-        # (see _HipTrunk; 52 ms vs 98 ms per 72-clip step); "torch" = everything on PyTorch-ROCm autograd
-        # "hip-strict" = as "hip", but raise instead of warning when a call cannot take the hand-written trunk
+        # training (grad enabled, model.train()):
+        #   "hip" (default; "hip-strict" is an alias) = conv trunk forward + backward in libmst.so (see _HipTrunk); a call the
+        #                    hand-written trunk cannot take raises RuntimeError naming the reason -- nothing falls back silently
+        #   "torch"        = explicit opt-in: everything on PyTorch-ROCm autograd (BASELINE configs[1] / A-B comparisons)
+        #   "hip-or-torch" = explicit opt-in: as "hip", but a refused call warns once per reason and runs on PyTorch-ROCm autograd
         self.train_backend = "hip"
         # precision of the hand-written training trunk: "fp32" (exact), "f16" (float16 operands, fp32 accumulation:
         # the reference's --use_amp arithmetic, see include/mst.h mst_encoder_set_train_precision), "f16x3" (the same
@@ -784,9 +788,10 @@ class MixingStyleEncoder(nn.Module):
         # single-process reference computes on the whole batch; a DistSync-like object = that, over its group
         self.sync_bn = False
         self._warned = set()
+        self._stats_epoch = 0   # bumped whenever a kernel rewrites BatchNorm buffers through raw pointers (no tensor._version bump)
 
     def _params_version(self):
-        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        return tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers()) + (self._stats_epoch,)
 
     def hip_encoder(self) -> HipEncoder:
         v = self._params_version() + (self.conv1_precision,)
@@ -869,7 +874,7 @@ class MixingStyleEncoder(nn.Module):
             logmel = logmel.to_reference()   # (a caller's own LogMel in a layout this precision mode does not read)
         cn = ae.subnet_cnns
         trunk_flat, trunk_params = self._trunk_flat()
-        hip_small = self._small_nets_in_hip(mixing_features)
+        hip_small = self._small_nets_in_hip(mixing_features, (logmel.frames if isinstance(logmel, LogMel) else logmel.shape[-1]) // 20)
         if hip_small:   # FiLM MLP forward / backward in libmst.so (csrc/head.hip)
             mlp = fe.feature_mlp
             flat = _HipFilmMLP.apply(mixing_features, float(mlp[2].p) if self.training else 0.0, mlp[0].weight, mlp[0].bias,
@@ -897,6 +902,7 @@ class MixingStyleEncoder(nn.Module):
                 for layer, name in ((1, "bn1"), (2, "bn2")):
                     rm, rv, nb = self._bn_flat(name)
                     enc.update_running_stats(layer, B, Fr, rm, rv, nb, next(iter(mom[name])), cross_rank=sync is not None)
+                self._stats_epoch += 1   # the kernel wrote the buffers behind autograd's back: the eval encoder's BatchNorm fold is stale
             else:
                 pool_in, bn1, bn2 = out
                 if sync is not None:   # the GLOBAL clip count, as the ranks summed it next to the statistics (ranks may hold different
@@ -946,46 +952,55 @@ class MixingStyleEncoder(nn.Module):
     # "torch" = the nn.Modules with autograd
     small_nets_backend = "hip"
 
-    def _small_nets_in_hip(self, mixing_features):
+    def _small_nets_in_hip(self, mixing_features, pooled_frames=1):
         ap, fe = self.audio_encoder.attention_pooling, self.film_encoder
         return (self.small_nets_backend == "hip" and not mixing_features.requires_grad and mixing_features.is_cuda
                 and ap.attention[0].out_features <= 256 and ap.input_dim <= 3072 and fe.feature_dim <= 2048
+                and pooled_frames <= 2048   # csrc/head.hip kHeadMaxFrames (LDS rows of the softmax / pooling kernels)
                 and fe.feature_mlp[0].out_features <= 2048
                 and all(q.dtype == torch.float32 for q in (ap.attention[0].weight, fe.film_head.weight)))
 
-    def _hip_trunk_refusal(self, logmel):
-        """Why the hand-written training trunk cannot take this call (None = it can)."""
+    _HIP_TRAIN_BACKENDS = ("hip", "hip-strict", "hip-or-torch")
+
+    def _hip_trunk_refusal_for(self, frames, on_gpu, logmel_dtype=torch.float32):
+        """Why the hand-written training trunk cannot take a call with this many frames (None = it can).  ONE predicate for
+        `forward` (which must choose stage A's output layout before the log-mel exists) and `forward_from_logmel`."""
         if self.audio_encoder.split_size // 10 not in (1, 2):
             return f"split_size={self.audio_encoder.split_size}: the training kernels cover first-pool heights 1 and 2"
-        cm = isinstance(logmel, LogMel)
-        frames = logmel.frames if cm else logmel.shape[-1]
-        if not (logmel.data if cm else logmel).is_cuda:
+        if not on_gpu:
             return "log-mel is not on the GPU"
         if frames < 20:
             return f"{frames} frames < 20"
-        if (not cm and logmel.dtype != torch.float32) or self.film_encoder.film_head.weight.dtype != torch.float32:
-            return f"non-fp32 tensors (log-mel {logmel.dtype}, parameters {self.film_encoder.film_head.weight.dtype})"
+        if logmel_dtype != torch.float32 or self.film_encoder.film_head.weight.dtype != torch.float32:
+            return f"non-fp32 tensors (log-mel {logmel_dtype}, parameters {self.film_encoder.film_head.weight.dtype})"
         return None
 
+    def _hip_trunk_refusal(self, logmel):
+        cm = isinstance(logmel, LogMel)
+        return self._hip_trunk_refusal_for(logmel.frames if cm else logmel.shape[-1], (logmel.data if cm else logmel).is_cuda,
+                                           torch.float32 if cm else logmel.dtype)
+
     def forward_from_logmel(self, logmel, mixing_features):
+        if self.train_backend not in self._HIP_TRAIN_BACKENDS + ("torch",):
+            raise ValueError("train_backend must be 'hip' (default; alias 'hip-strict'), 'torch' or 'hip-or-torch'")
         auto = self._needs_autograd(mixing_features)
-        hip_train = self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict")
-        if isinstance(logmel, LogMel) and not (self.encoder_backend == "hip" and not auto and not self.training) and \
-                not (hip_train and self._hip_trunk_refusal(logmel) is None):
-            logmel = logmel.to_reference()   # only the eval forward and the float16 training trunk in libmst.so read channel-minor layouts
-        if hip_train:
+        hip_train = self.encoder_backend == "hip" and self.training and auto and self.train_backend in self._HIP_TRAIN_BACKENDS
+        if hip_train:   # decided BEFORE any layout conversion, so that a refusal names its reason
             why = self._hip_trunk_refusal(logmel)
             if why is None:
                 return self._forward_train_hip(logmel, mixing_features)
-            msg = (f"MixingStyleEncoder: training forward leaves the hand-written HIP trunk ({why}); running the conv stack "
-                   f"on PyTorch-ROCm/MIOpen autograd instead (about 2x the step time, library numerics)")
-            if self.train_backend == "hip-strict":
-                raise RuntimeError(msg)
+            msg = f"MixingStyleEncoder: the hand-written HIP training trunk cannot take this call ({why})"
+            if self.train_backend != "hip-or-torch":
+                raise RuntimeError(msg + "; train_backend='torch' (or 'hip-or-torch') runs the conv stack on PyTorch-ROCm/MIOpen "
+                                         "autograd instead (about 2x the step time, library numerics)")
             if self.sync_bn:   # the decision is per rank: a rank that fell back would skip the statistics all-reduces its peers
                 raise RuntimeError(msg + " -- refused with sync_bn: the other ranks would wait in their collectives forever")
             if why not in self._warned:
                 self._warned.add(why)
-                warnings.warn(msg, RuntimeWarning, stacklevel=2)
+                warnings.warn(msg + "; running the conv stack on PyTorch-ROCm/MIOpen autograd (train_backend='hip-or-torch')",
+                              RuntimeWarning, stacklevel=2)
+        if isinstance(logmel, LogMel) and not (self.encoder_backend == "hip" and not auto and not self.training):
+            logmel = logmel.to_reference()   # only the eval forward and the hand-written training trunk read channel-minor layouts
         if auto and self.training and self.sync_bn and "sync_bn" not in self._warned:
             self._warned.add("sync_bn")
             warnings.warn("MixingStyleEncoder.sync_bn is implemented by the hand-written HIP trunk only; this call runs the conv "
@@ -1017,9 +1032,11 @@ class MixingStyleEncoder(nn.Module):
             want = self.hip_encoder().preferred_layout()
             if plan.supports_layout(want):
                 layout, want_lo = want, self.hip_encoder().mode != 3   # (plain float16: the high parts alone)
-        elif self.encoder_backend == "hip" and self.training and auto and self.train_backend in ("hip", "hip-strict") and \
-                self.audio_encoder.split_size // 10 in (1, 2):
-            # the float16 training trunk reads stage A's float16 planes (conv1 forward and its weight gradient)
+        elif self.encoder_backend == "hip" and self.training and auto and self.train_backend in self._HIP_TRAIN_BACKENDS and \
+                self._hip_trunk_refusal_for(1 + next(iter(stems_dict.values())).shape[-1] // pre.hop_length,
+                                            next(iter(stems_dict.values())).is_cuda) is None:
+            # the float16 training trunk reads stage A's float16 planes (conv1 forward and its weight gradient); the SAME predicate
+            # as forward_from_logmel's, so a high-parts-only LogMel is only ever produced for a call the trunk will take
             want = self._train_encoder().train_layout()
             if plan.supports_layout(want):
                 layout, want_lo = want, self._train_encoder().train_mode != 1   # (f16 mode: the high parts alone)

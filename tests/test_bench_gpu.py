@@ -34,6 +34,21 @@ def test_contract_line_hip_encoder():
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and 0 < rf["stage_a_hbm_frac"] < 1
     assert rf["stage_b_tflops"] <= rf["stage_b_tflops_algorithmic"] < 157.3       # executed <= reference's flop count
     assert "alt" in out and isinstance(out["alt"], list)
+    # the timed workload is checked after timing: every clip bit-equal to its B = 1 run (no oracle here: --no-cpu-baseline)
+    v = out["config"]["verified"]
+    assert v["ok"] and v["batch_independence"]["bit_equal"] == v["clips"] == out["config"]["clips_per_gpu"]
+    assert out["ms_per_step_median"] > 0
+    for row in out["alt"]:
+        assert "error" not in row, row
+        assert row["verified"]["ok"] and row["embedding_error_vs_fp32_kernels"]["normwise"] < (1e-5 if "f16x3" in row["mode"] else 2e-3)
+        assert 0 < row["roofline"]["conv1_frac"] < 1
+
+
+def test_contract_line_with_cpu_baseline_checks_against_the_oracle():
+    out = _bench(["--steps", "2", "--warmup", "1", "--triplets", "2", "--seconds", "2"])
+    v = out["config"]["verified"]
+    assert v["ok"] and v["oracle"]["beyond_tol"] == 0 and v["oracle"]["max_rel"] <= 1e-4 and len(v["oracle"]["clips"]) == 3
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
 
 
 def test_configs1_torch_encoder_line():
@@ -46,6 +61,9 @@ def test_gpus_2_launches_two_ranks_itself():
     out = _bench(["--gpus", "2"] + SMALL, MST_BENCH_ONE_GPU="1", MST_BENCH_BACKEND="gloo")
     assert out["n_gpus"] == 2 and out["world"] == 2 and out["rccl_ranks_seen"] == 2
     assert out["config"]["parallelism"] == "clip-sharded x2" and "cpu_baseline" not in out
+    mg = out["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step_wall"]) == 2 and mg["all_gather_ms"]["max"] >= 0 and 0 <= mg["all_gather_share_of_step"] < 1
+    assert out["config"]["verified"]["ok"] and out["config"]["verified"]["ok_all_ranks"]
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "amp"])

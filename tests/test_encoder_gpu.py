@@ -149,9 +149,27 @@ def test_torch_backend_agrees_and_train_mode_guard():
     model.train()
     with torch.no_grad(), pytest.raises(RuntimeError):
         model.forward_from_logmel(lm, feats)
-    out = model.forward_from_logmel(lm, feats)      # grad enabled + train(): PyTorch-ROCm autograd path
+    model.train_backend = "torch"                   # explicit opt-in: grad enabled + train() on PyTorch-ROCm autograd
+    out = model.forward_from_logmel(lm, feats)
     out.sum().backward()
     assert model.film_encoder.film_head.weight.grad is not None
+    # the default backend never leaves the hand-written trunk silently: a call it cannot take (here: 40-mel sub-bands, first-pool
+    # height 4) raises and names the reason, from forward_from_logmel and from forward alike; "hip-or-torch" is the explicit
+    # warn-and-fall-back opt-in
+    from mst_amd.model import MixingStyleEncoder
+    m40 = MixingStyleEncoder(n_mels=128, split_size=40, overlap=20, feature_dim=64).cuda().train()
+    assert m40.train_backend == "hip"
+    with pytest.raises(RuntimeError, match="first-pool heights 1 and 2"):
+        m40.forward_from_logmel(lm, feats)
+    with pytest.raises(RuntimeError, match="first-pool heights 1 and 2"):
+        m40(omel.tensor_to_stems_dict(x), feats)
+    m40.train_backend = "hip-or-torch"
+    with pytest.warns(RuntimeWarning, match="first-pool heights 1 and 2"):
+        out = m40(omel.tensor_to_stems_dict(x), feats)
+    assert torch.isfinite(out).all()
+    m40.train_backend = "nonsense"
+    with pytest.raises(ValueError):
+        m40.forward_from_logmel(lm, feats)
 
 
 def test_unsupported_geometry_fails_loudly():

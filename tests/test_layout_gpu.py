@@ -321,6 +321,32 @@ def test_eval_encoder_is_refreshed_on_the_device_after_parameter_updates(precisi
         assert (e_after - e_fresh).abs().max().item() <= 2e-6 * e_fresh.abs().max().item()
 
 
+def test_eval_encoder_sees_running_statistics_updated_without_an_optimizer_step():
+    """BatchNorm recalibration / a GradScaler-skipped step right before validation: train-mode forwards move the running
+    statistics (written by `mst_encoder_train_update_running_stats` through raw pointers, which bumps no tensor version) while no
+    parameter changes.  The next eval forward must fold the NEW statistics -- equal to the PyTorch-ROCm backend's eval forward of the
+    same module, and different from the embeddings before the recalibration."""
+    cfg = cases.CFG_DEFAULT
+    m = _build(cfg, "fp32")
+    d = _stems(3, 44100, seed=11)
+    feats = torch.randn(3, 64, generator=torch.Generator().manual_seed(2)).cuda()
+    with torch.no_grad():
+        e_before = m(d, feats).clone()
+    rm_before = m.audio_encoder.subnet_cnns[3].bn1.running_mean.clone()
+    m.train()
+    for _ in range(3):               # forward only: no backward, no optimizer step
+        m(d, feats)
+    m.eval()
+    assert (m.audio_encoder.subnet_cnns[3].bn1.running_mean - rm_before).abs().max() > 1e-3, "the statistics did move"
+    with torch.no_grad():
+        e_after = m(d, feats)
+        m.encoder_backend = "torch"
+        e_torch = m(d, feats)
+        m.encoder_backend = "hip"
+    assert (e_after - e_before).abs().max() > 1e-4 * e_before.abs().max(), "the eval encoder still folds the old statistics"
+    assert (e_after - e_torch).abs().max().item() <= 1e-4 * e_torch.abs().max().item()
+
+
 def test_plain_float16_consumers_get_the_high_parts_alone():
     """`forward_stems(..., LOGMEL_CM16, want_lo=False)`: stage A writes the float16 high parts only (the plain-float16 eval mode and
     the f16 training mode read nothing else) -- same bits as with the low parts, a quarter of the log-mel bytes less to write and to

@@ -66,6 +66,12 @@ def _worker(rank, world, port, precision, ret, backend="gloo"):
                        if a.dtype.is_floating_point)
             ret["loss"] = abs(tot.item() - lw.item()) / abs(lw.item())
             ret["worst"], ret["stat"] = worst, stat
+        # the same step with .grad tensors that already exist (zeroed in place): autograd accumulates into them instead of adopting
+        # the trunk's stacked views, and the reducer must still leave the reduced gradients there (it used to leave the local ones)
+        model.zero_grad(set_to_none=False)
+        (model.forward_from_logmel(lm[sl].contiguous(), feats[sl]) * R[sl]).sum().backward()
+        red.wait()
+        ret[f"inplace_equal_{rank}"] = all(torch.equal(p.grad, grads[n]) for n, p in model.named_parameters())
     finally:
         dist.destroy_process_group()
 
@@ -82,6 +88,7 @@ def test_two_rank_step_with_sync_bn_equals_the_single_process_step(precision):
     tol = 1e-4 if precision == "fp32" else 3e-2   # f16: per-rank range scales move single float16 roundings
     print(f"sync_bn, 2 ranks, {precision}: loss {ret['loss']:.2e}, worst gradient {ret['worst']}, running statistics {ret['stat']:.2e}")
     assert ret["loss"] < (1e-5 if precision == "fp32" else 1e-3) and ret["worst"][0] < tol and ret["stat"] < 1e-4, dict(ret)
+    assert ret.get("inplace_equal_0") and ret.get("inplace_equal_1"), "zero_grad(set_to_none=False): reduced gradients must be bit-equal to the first step's"
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank; this box has one")
