@@ -1279,6 +1279,12 @@ bool v2_build_segments(mst_plan* p, const float* fb, std::vector<float2>& segw, 
   return true;
 }
 
+// the piece table has the shape melfeat_v2_kernel<..., STD> hard-codes (the 128-mel HTK filterbank at 44.1 kHz / n_fft 1024)
+bool v2_table_is_standard(const mst_plan* p) {
+  return p->n_mels == 128 && p->v2_nslot == 3 && p->v2_maxcnt == 1 && p->v2_glen[0] == 14 && p->v2_glen[1] == 3 && p->v2_glen[2] == 0 &&
+         p->v2_goff[0] == 0 && p->v2_goff[1] == 14 && p->v2_goff[2] == 17;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1595,7 +1601,10 @@ int melfeat_forward_impl(const mst_plan* p, const void* const stems4[4], bool pc
     MST_REQUIRE(lds2 <= 160 * 1024, "mst_melfeat_forward: LDS %zu B exceeds 160 KiB", lds2);
     const int grid2 = B * k2.runs_per_clip;
     if (wide) e = pcm16 ? launch_melfeat_v2<short, 2, 4>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 2, 4>(k2, grid2, lds2, st);
-    else if (wps == 3) e = pcm16 ? launch_melfeat_v2<short, 3>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 3>(k2, grid2, lds2, st);
+    else if (wps == 3) {
+      const bool stdt = v2_table_is_standard(p) && !getenv("MST_V2_NOSTD");
+      e = pcm16 ? launch_melfeat_v2<short, 3>(k2, grid2, lds2, st, stdt) : launch_melfeat_v2<float, 3>(k2, grid2, lds2, st, stdt);
+    }
     else e = pcm16 ? launch_melfeat_v2<short, 2>(k2, grid2, lds2, st) : launch_melfeat_v2<float, 2>(k2, grid2, lds2, st);
   } else {
   const int grid = B * kp.runs_per_clip;
