@@ -351,10 +351,12 @@ int mst_encoder_train_conv2_dgrad(const mst_encoder* enc, const float* dy2, int 
 typedef struct mst_aug_stem {
   float gain;          /* linear gain, 1.0f = none             (:389-392)                   */
   int32_t tilt;        /* 0 none, 1 section in tilt_sos        (:421-433)                   */
-  int32_t compress;    /* 0/1: 4:1 above -20 dB                (:435-447)                   */
+  int32_t compress;    /* 0 none; 1: the reference's default 4:1 above -20 dB; 2: comp_threshold_db / comp_ratio (:435-447) */
   int32_t bw_sections; /* 0 none, else #biquads in bw_sos (2)  (:449-456)                   */
   double tilt_sos[6];  /* scipy.signal.butter(..., output='sos') rows b0 b1 b2 a0 a1 a2     */
   double bw_sos[12];
+  float comp_threshold_db; /* compress == 2: apply_compression(audio, threshold, ratio), threshold in dB ... */
+  float comp_ratio;        /* ... and ratio > 0                                               */
 } mst_aug_stem;
 
 typedef struct mst_aug_clip {

@@ -62,7 +62,7 @@ class EncoderTrainTaps(C.Structure):
 
 class AugStem(C.Structure):
     _fields_ = [("gain", C.c_float), ("tilt", C.c_int32), ("compress", C.c_int32), ("bw_sections", C.c_int32),
-                ("tilt_sos", C.c_double * 6), ("bw_sos", C.c_double * 12)]
+                ("tilt_sos", C.c_double * 6), ("bw_sos", C.c_double * 12), ("comp_threshold_db", C.c_float), ("comp_ratio", C.c_float)]
 
 
 class AugClip(C.Structure):

@@ -3,13 +3,10 @@
 // :435-447, apply_bandwidth_limit :449-456, apply_reverb :458-479.  All random decisions (coins, gain, cutoff,
 // impulse response) are drawn by the host in the reference's order and arrive in `mst_aug_clip` / `reverb_ir`.
 //
-//   aug_tilt_zs / aug_scan<0> / aug_tilt_resp / aug_scan<1> / aug_bw_resp: x*gain -> biquad (tilt) -> compressor
-//                      -> 1-2 biquads (low-pass), thread per 512-sample chunk, float64 block-parallel IIR.
-//                      scipy.signal.sosfilt is a sequential fp64 DF2T recurrence; here the channel is cut into
-//                      512-sample chunks and solved as a block-parallel state-space scan in fp64:
-//                      (1) zero-state response of every chunk in parallel, (2) serial carry of the chunk-boundary
-//                      states with A^512, (3) every chunk re-run from its true initial state.  Rounded to fp32
-//                      exactly where the reference calls `.float()`.
+//   aug_chain_kernel   x*gain -> biquad (tilt) -> compressor -> 1-2 biquads (low-pass): one workgroup per channel, segments of
+//                      32 768 samples resident in LDS, float64 block-parallel IIR inside a segment (see the kernel's comment);
+//                      one read and one write of every channel that has a decision.  scipy.signal.sosfilt is a sequential
+//                      fp64 DF2T recurrence; rounded to fp32 exactly where the reference calls `.float()`.
 //   aug_energy_kernel  per-stem mean square for the reverb redistribution weights (:410-416).
 //   reverb             y[n] = sum_k ir[k] * mix[n + k - L/2]  (F.conv1d = cross-correlation, :468-474) as a uniformly
 //                      partitioned overlap-save convolution: 1024-point wave-level FFTs of 512-sample blocks of
@@ -25,37 +22,76 @@ namespace {
 
 using namespace mstfft;
 
-constexpr int kLc = 512;      // IIR chunk length
 constexpr int kBlk = 512;     // overlap-save block (FFT size 1024)
 constexpr int kNfft = 1024;
 
+struct ChainCarry {           // what segment k of a stream hands to segment k + 1: the filter states after its last sample.  Every word
+  unsigned long long t[2], b[4], pad_[2];   // starts as kCarryEmpty and is written ONCE, with one 64-bit agent-scope atomic store
+};
+constexpr unsigned long long kCarryEmpty = ~0ull;   // (all ones: a NaN pattern no arithmetic produces; hipMemset 0xFF)
 struct ChainParams {
   float* stems;              // [B][8][T]
   const mst_aug_clip* dec;   // device copy [B]
-  double* states;            // [B][8][nchunk][4]
-  int T, nchunk;
+  int T;
   long long clip_stride;     // floats between clips (8 * T when packed)
+  int B, nseg;
+  int* act;                  // [1 + B * 8]: number of streams with a decision, then their indices (aug_active_kernel)
+  int* ticket;               // [2]: work-item counter, error word (zeroed per launch)
+  ChainCarry* carry;         // [B * 8][nseg] (zeroed per launch)
 };
 
-// mixing_utils.py:435-447 (threshold -20 dB, ratio 4): dB = 20 log10(|x| + 1e-8); above -20 dB: dB' = -20 + (dB + 20) / 4;
-// y = sign(x) 10^(dB' / 20).  In closed form, with a = |x| + 1e-8:  a <= 0.1 -> y = sign * a (the 1e-8 offset survives, as in
-// the reference);  a > 0.1 -> y = sign * 10^(-3/4) * a^(1/4).  Two square roots instead of log10f + powf: ~10 instructions
-// instead of ~100, and closer to the real-valued result than the reference's own float32 log / pow chain (which it matches to
-// a few 1e-7 relative; the goldens hold at 1e-5).
-__device__ __forceinline__ float compress_f32(float x) {
+// mixing_utils.py:435-447:  dB = 20 log10(|x| + 1e-8);  above the threshold: dB' = thr + (dB - thr) / ratio;  y = sign(x) 10^(dB' / 20).
+// In closed form, with a = |x| + 1e-8 and t = 10^(thr / 20):  a <= t -> y = sign * a (the 1e-8 offset survives, as in the
+// reference);  a > t -> y = sign * 10^(thr (1 - 1/ratio) / 20) * a^(1 / ratio).
+//   mode 1  the reference's default setting (-20 dB, 4:1): 10^(-3/4) * a^(1/4) as two square roots instead of log10f + powf -- ~10
+//           instructions instead of ~100, and closer to the real-valued result than the reference's own float32 log / pow chain
+//           (which it matches to a few 1e-7 relative; the goldens hold at 1e-5);
+//   mode 2  any threshold / ratio (mst_aug_stem.comp_threshold_db / comp_ratio): the constants come from the host in double.
+struct Comp {
+  int mode;
+  float lin_thr, c, inv_ratio;
+};
+__device__ __forceinline__ float compress_f32(float x, const Comp& k) {
   const float a = fabsf(x) + 1e-8f;
-  const float y = a > 0.1f ? 0.17782794100389228f * sqrtf(sqrtf(a)) : a;
+  float y;
+  if (k.mode == 1) y = a > 0.1f ? 0.17782794100389228f * sqrtf(sqrtf(a)) : a;
+  else y = a > k.lin_thr ? k.c * powf(a, k.inv_ratio) : a;
   return x > 0.f ? y : (x < 0.f ? -y : 0.f);
 }
+__device__ __forceinline__ Comp comp_of(const mst_aug_stem& d) {
+  Comp k{d.compress, 0.1f, 0.17782794100389228f, 0.25f};
+  if (d.compress == 2) {
+    const double thr = (double)d.comp_threshold_db, ir = 1.0 / (double)d.comp_ratio;
+    k.lin_thr = (float)pow(10.0, thr / 20.0), k.c = (float)pow(10.0, thr * (1.0 - ir) / 20.0), k.inv_ratio = (float)ir;
+  }
+  return k;
+}
 
-// ---- block-parallel IIR: chunk c of a stream = samples [c*kLc, (c+1)*kLc).
-//   zero-state pass (thread per chunk)  ->  z_c = final filter state of the chunk started from rest
-//   scan (one wave per stream)          ->  start state of every chunk: s_{c+1} = A^kLc s_c + z_c
-//   response pass (thread per chunk)    ->  true output from the start state
-// The chain is: x*gain -> [tilt biquad] -> [compressor] -> store -> [1-2 low-pass biquads]; the tilt response pass
-// also runs the low-pass zero-state pass on the values it has just produced (one read of the waveform less).
-// Every sample goes through exactly the reference's arithmetic (float64 DF2T, scipy sosfilt order, `.float()` after
-// each filter, mixing_utils.py:421-456); only the chunk start states are obtained differently.
+// ---- the IIR chain  x * gain -> [tilt biquad] -> [compressor] -> [1-2 low-pass biquads]  (mixing_utils.py:389-456) in ONE kernel.
+// scipy.signal.sosfilt is a sequential float64 DF2T recurrence over the whole channel.  Here ONE WORKGROUP owns one channel
+// ("stream") and walks it in segments of 32 768 samples that live in LDS: the segment is read from HBM once (whole 128-byte
+// lines), every pass over it reads and writes LDS, and it is written back once -- the chain moves its algorithmic bytes, one
+// read and one write of every stream that has a decision (the three-launch form of round 3 read a filtered stream three times
+// and wrote it twice).  Inside a segment the recurrences are block-parallel, exactly as before: a thread owns a chunk of 64
+// consecutive samples;
+//   (1) zero-state pass: the chunk's final filter state when started from rest (z_c);
+//   (2) scan: start state of every chunk, s_c = M^c s_seg + sum_{j<c} M^(c-1-j) z_j with M = A^64 (the homogeneous transition
+//       of a chunk), as a doubling prefix inside each wave (shared powers M^1 .. M^32 in LDS), a serial carry over the 8 waves
+//       (M^64) and a lane-dependent power M^lane of the wave's carry;  the state after the last chunk seeds the next segment;
+//   (3) response pass: every chunk re-run from its true start state -- the reference's arithmetic sample for sample (float64
+//       DF2T, sosfilt's section order, `.float()` after each filter); only the chunk start states are obtained differently.
+// The tilt response pass also applies gain and compressor and runs the low-pass zero-state pass on the values it has just
+// produced.  The next segment's samples are loaded into registers while this one is processed.
+#ifndef MST_AUG_FT
+#define MST_AUG_FT 512
+#define MST_AUG_FL 64
+#define MST_AUG_FB 16
+#endif
+constexpr int kFT = MST_AUG_FT, kFL = MST_AUG_FL, kFS = kFT * kFL, kFP = kFL + 1;   // threads, samples per chunk, samples per segment, LDS row pitch
+constexpr int kFW = kFT / 64, kFB = MST_AUG_FB;
+constexpr int kFPow = (kFT == 1024 ? 10 : kFT == 512 ? 9 : 8) + 1;    // powers M^(2^k) kept: the last one spans a whole segment
+static_assert((1 << (kFPow - 1)) == kFT, "kFT must be 256, 512 or 1024");                               // waves; samples per register batch of the serial walks
+
 struct Coef {   // one biquad of an sos row {b0,b1,b2,a0,a1,a2}: b0, b1, b2, a1, a2
   double b0, b1, b2, a1, a2;
 };
@@ -67,323 +103,270 @@ __device__ __forceinline__ double biquad_step(const Coef& c, double& s0, double&
   return y;
 }
 
-// walk one chunk 4 samples at a time (16-byte loads, next group prefetched) or sample by sample when the chunk is
-// ragged / unaligned; f(value) returns the value to store, STORE selects whether it is written back
-template <bool STORE, typename F>
-__device__ __forceinline__ void walk_chunk(float* x, int n0, int n1, F&& f) {
-  if (n1 - n0 == kLc && (reinterpret_cast<uintptr_t>(x + n0) & 15) == 0) {
-    float4 cur = *reinterpret_cast<const float4*>(x + n0);
-#pragma unroll 2
-    for (int i = 0; i < kLc; i += 4) {
-      const float4 nxt = *reinterpret_cast<const float4*>(x + n0 + min(i + 4, kLc - 4));
-      float4 o;
-      o.x = f(cur.x), o.y = f(cur.y), o.z = f(cur.z), o.w = f(cur.w);
-      if (STORE) *reinterpret_cast<float4*>(x + n0 + i) = o;
-      cur = nxt;
-    }
-  } else {
-    for (int n = n0; n < n1; ++n) {
-      const float o = f(x[n]);
-      if (STORE) x[n] = o;
-    }
-  }
-}
+struct ChainLds {
+  float tile[kFT * kFP];
+  double Mp[2][kFPow][16]; // [filter: 0 tilt, 1 low-pass][k][4 x 4]: M^(2^k), k = 0 .. log2(kFT), zero outside the D x D block
+  double wtot[kFW][4];     // inclusive prefix of every wave's last lane
+  double seg[4];           // state at the start of this segment (from the previous segment's workgroup)
+  int item;                // this workgroup's ticket
+};
 
-// grid (ceil(nchunk/256), B*8): zero-state pass of the tilt biquad on x*gain
-__global__ __launch_bounds__(256) void aug_tilt_zs_kernel(const ChainParams p) {
-  const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
-  if (d.tilt == 0 || c >= p.nchunk) return;
-  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
-  const Coef k = coef_of(d.tilt_sos);
-  const float gain = d.gain;
-  double s0 = 0.0, s1 = 0.0;
-  walk_chunk<false>(x, c * kLc, min(p.T, (c + 1) * kLc), [&](float v) {
-    (void)biquad_step(k, s0, s1, (double)(v * gain));
-    return 0.f;
-  });
-  double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
-  st[0] = s0, st[1] = s1;
-}
-
-// grid (B*8), one wave: chunk start states from the zero-state finals.  WHICH 0: tilt (1 section), 1: low-pass (1-2).
-// Two levels: every lane folds its G = ceil(nchunk/64) consecutive chunks, lane 0 chains the 64 groups with M^G, every
-// lane then replays its chunks from its group's start state (serial depth 2G + 64 instead of nchunk).
-template <int WHICH>
-__global__ __launch_bounds__(64) void aug_scan_kernel(const ChainParams p) {
-  __shared__ double Msh[16], MGsh[16], agg[64 * 4], cin[64 * 4];
-  const int stream = blockIdx.x, lane = threadIdx.x;
-  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
-  const int NS = WHICH == 0 ? (d.tilt != 0 ? 1 : 0) : d.bw_sections;
-  if (NS == 0) return;   // block-uniform
+// powers M^(2^k), k = 0 .. kFPow - 1, of the chunk transition of a cascade of NS biquads (D = 2 NS states) into Mp[.][16]
+__device__ __forceinline__ void chain_powers(double (*Mp)[16], const double* sos, int NS, int tid) {
   const int D = 2 * NS;
-  const double* sos = WHICH == 0 ? d.tilt_sos : d.bw_sos;
-  double* st = p.states + (size_t)stream * p.nchunk * 4;
-  if (lane < 16) Msh[lane] = 0.0;
+  if (tid < 16) Mp[0][tid] = 0.0;
   __syncthreads();
-  // M = A^kLc, one column per lane: homogeneous response to a unit initial state
-  if (lane < D) {
+  if (tid < D) {   // column tid of M = A^kFL: homogeneous response to a unit initial state
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < 4; ++i) s[i] = (i == lane) ? 1.0 : 0.0;
+    for (int i = 0; i < 4; ++i) s[i] = (i == tid) ? 1.0 : 0.0;
     const Coef k0 = coef_of(sos), k1 = coef_of(sos + (NS > 1 ? 6 : 0));
-    for (int n = 0; n < kLc; ++n) {
+    for (int n = 0; n < kFL; ++n) {
       double v = biquad_step(k0, s[0], s[1], 0.0);
       if (NS > 1) v = biquad_step(k1, s[2], s[3], v);
     }
-    for (int i = 0; i < D; ++i) Msh[i * 4 + lane] = s[i];
+    for (int i = 0; i < D; ++i) Mp[0][i * 4 + tid] = s[i];
   }
   __syncthreads();
-  double M[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) M[i][j] = Msh[i * 4 + j];   // zero outside the D x D block
-  const int G = (p.nchunk + 63) / 64;
-  const int c0 = min(p.nchunk, lane * G), c1 = min(p.nchunk, c0 + G);
-  auto step = [&](double (&a)[4], int c) {   // a <- M a + z_c
-    double nx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double t = i < D ? st[(size_t)c * 4 + i] : 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t += M[i][j] * a[j];
-      nx[i] = t;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = nx[i];
-  };
-  // (1) fold this lane's chunks from rest; lane 0 also forms M^G
-  double a[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int c = c0; c < c1; ++c) step(a, c);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) agg[lane * 4 + i] = a[i];
-  if (lane == 0) {
-    double P[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) P[i][j] = M[i][j];
-    for (int g = 1; g < G; ++g) {
-      double Q[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          double t = 0.0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) t += M[i][k] * P[k][j];
-          Q[i][j] = t;
-        }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) P[i][j] = Q[i][j];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) MGsh[i * 4 + j] = P[i][j];
-  }
-  __syncthreads();
-  // (2) chain the 64 groups
-  if (lane == 0) {
-    double cr[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int g = 0; g < 64; ++g) {
-      double nx[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        cin[g * 4 + i] = cr[i];
-        double t = agg[g * 4 + i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t += MGsh[i * 4 + j] * cr[j];
-        nx[i] = t;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) cr[i] = nx[i];
-    }
-  }
-  __syncthreads();
-  // (3) start state of every chunk of the group (overwrites z_c)
-  double sv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sv[i] = cin[lane * 4 + i];
-  for (int c = c0; c < c1; ++c) {
-    double keep[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) keep[i] = sv[i];
-    step(sv, c);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < D) st[(size_t)c * 4 + i] = keep[i];
-  }
-}
-
-// grid (ceil(nchunk/256), B*8): gain -> tilt response -> compressor -> store, then the low-pass zero-state pass on
-// the stored values
-__global__ __launch_bounds__(256) void aug_tilt_resp_kernel(const ChainParams p) {
-  const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
-  const bool has_g = d.gain != 1.0f, has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
-  if (!(has_g || has_t || has_c || has_b) || c >= p.nchunk) return;
-  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
-  double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
-  const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
-  double t0 = has_t ? st[0] : 0.0, t1 = has_t ? st[1] : 0.0;
-  double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-  const float gain = d.gain;
-  const bool two = d.bw_sections > 1;
-  auto body = [&](float v) {
-    float y = v * gain;
-    if (has_t) y = (float)biquad_step(kt, t0, t1, (double)y);
-    if (has_c) y = compress_f32(y);
-    if (has_b) {
-      const double w = biquad_step(kb0, b0, b1, (double)y);
-      if (two) (void)biquad_step(kb1, b2, b3, w);
-    }
-    return y;
-  };
-  const int n0 = c * kLc, n1 = min(p.T, n0 + kLc);
-  if (has_g || has_t || has_c) walk_chunk<true>(x, n0, n1, body);
-  else walk_chunk<false>(x, n0, n1, body);
-  if (has_b) st[0] = b0, st[1] = b1, st[2] = b2, st[3] = b3;
-}
-
-// grid (ceil(nchunk/256), B*8): low-pass response from the scanned start states
-__global__ __launch_bounds__(256) void aug_bw_resp_kernel(const ChainParams p) {
-  const int stream = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
-  if (d.bw_sections <= 0 || c >= p.nchunk) return;
-  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
-  const double* st = p.states + ((size_t)stream * p.nchunk + c) * 4;
-  const Coef kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
-  const bool two = d.bw_sections > 1;
-  double b0 = st[0], b1 = st[1], b2 = two ? st[2] : 0.0, b3 = two ? st[3] : 0.0;
-  walk_chunk<true>(x, c * kLc, min(p.T, (c + 1) * kLc), [&](float v) {
-    double w = biquad_step(kb0, b0, b1, (double)v);
-    if (two) w = biquad_step(kb1, b2, b3, w);
-    return (float)w;
-  });
-}
-
-
-// ------------------------------------------------------------------------------------------
-// The three streaming passes of the IIR chain on LDS slabs (the aligned case: T % 4 == 0, 16-byte aligned base).
-// A thread still owns one 512-sample chunk and walks it serially in float64 -- but the samples no longer come from the
-// thread's own strided 16-byte loads / stores (64 lanes -> 64 different 128-byte lines per instruction, every line fetched
-// 8 times and written back in 8 partial pieces: the chain ran at 5 % of the HBM rate).  A workgroup = 256 consecutive chunks
-// of one stream; per step it moves a SLAB of 32 samples of each of its chunks: 8 consecutive threads read / write one whole
-// 128-byte run of a chunk, the slab is transposed through LDS ([256 chunks][33]: the thread of chunk r walks row r, stride
-// 33 words = no bank conflicts), the next slab's loads are in flight while this one is computed.
-//   PASS 0  zero-state pass of the tilt biquad on x * gain                                  (read only)
-//   PASS 1  gain -> tilt response -> compressor -> store; low-pass zero-state pass on the stored values   (read + write)
-//   PASS 2  low-pass response from the scanned start states                                   (read + write)
-// Same per-sample arithmetic as the chunk-walk kernels above (which stay as the path for unaligned lengths).
-// ------------------------------------------------------------------------------------------
-constexpr int kSlab = 32, kSlabRow = kSlab + 1, kWgChunks = 256;
-
-template <int PASS>
-__global__ __launch_bounds__(256) void aug_iir_pass_kernel(const ChainParams p) {
-  __shared__ float tile[2][kWgChunks * kSlabRow];
-  const int stream = blockIdx.y, tid = threadIdx.x;
-  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
-  const bool has_g = d.gain != 1.0f, has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
-  if (PASS == 0 && !has_t) return;                                   // block-uniform early outs
-  if (PASS == 1 && !(has_g || has_t || has_c || has_b)) return;
-  if (PASS == 2 && !has_b) return;
-  const int c0 = blockIdx.x * kWgChunks, c = c0 + tid;              // this thread's chunk
-  if (c0 >= p.nchunk) return;
-  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
-  const bool writes = PASS == 2 || (PASS == 1 && (has_g || has_t || has_c));
-  const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
-  const float gain = d.gain;
-  const bool two = d.bw_sections > 1;
-  double* st = p.states + ((size_t)stream * p.nchunk + min(c, p.nchunk - 1)) * 4;
-  double t0 = 0.0, t1 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-  if (PASS == 1 && has_t && c < p.nchunk) t0 = st[0], t1 = st[1];
-  if (PASS == 2 && c < p.nchunk) b0 = st[0], b1 = st[1], b2 = two ? st[2] : 0.0, b3 = two ? st[3] : 0.0;
-  // mover mapping: instruction i of a slab: chunk row 32 i + (tid >> 3), 16-byte part tid & 7
-  const int mrow = tid >> 3, mpart = tid & 7;
-  float4 reg[8];
-  auto load_slab = [&](int k) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int cc = c0 + 32 * i + mrow;
-      const long long n = (long long)cc * kLc + kSlab * k + 4 * mpart;
-      reg[i] = (cc < p.nchunk && n + 3 < p.T) ? *reinterpret_cast<const float4*>(x + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  load_slab(0);
-  for (int k = 0; k < kLc / kSlab; ++k) {
-    float* tl = tile[k & 1];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float* q = tl + (32 * i + mrow) * kSlabRow + 4 * mpart;
-      q[0] = reg[i].x, q[1] = reg[i].y, q[2] = reg[i].z, q[3] = reg[i].w;
+  for (int k = 1; k < kFPow; ++k) {
+    if (tid < 16) {
+      const int i = tid >> 2, j = tid & 3;
+      double t = 0.0;
+      for (int q = 0; q < 4; ++q) t += Mp[k - 1][i * 4 + q] * Mp[k - 1][q * 4 + j];
+      Mp[k][tid] = t;
     }
     __syncthreads();
-    if (k + 1 < kLc / kSlab) load_slab(k + 1);
-    {
-      float* row = tl + tid * kSlabRow;
-      const int nvalid = c < p.nchunk ? max(0, min(kSlab, p.T - (c * kLc + kSlab * k))) : 0;   // samples of this slab inside the clip
-      if (nvalid == kSlab) {
-#pragma unroll 4
-        for (int j = 0; j < kSlab; ++j) {
-          const float v = row[j];
-          if (PASS == 0) {
-            (void)biquad_step(kt, t0, t1, (double)(v * gain));
-          } else if (PASS == 1) {
-            float y = v * gain;
-            if (has_t) y = (float)biquad_step(kt, t0, t1, (double)y);
-            if (has_c) y = compress_f32(y);
-            if (has_b) {
-              const double w = biquad_step(kb0, b0, b1, (double)y);
-              if (two) (void)biquad_step(kb1, b2, b3, w);
-            }
-            row[j] = y;
-          } else {
-            double w = biquad_step(kb0, b0, b1, (double)v);
-            if (two) w = biquad_step(kb1, b2, b3, w);
-            row[j] = (float)w;
-          }
-        }
-      } else {
-        for (int j = 0; j < nvalid; ++j) {   // the clip's last, ragged chunk
-          const float v = row[j];
-          if (PASS == 0) {
-            (void)biquad_step(kt, t0, t1, (double)(v * gain));
-          } else if (PASS == 1) {
-            float y = v * gain;
-            if (has_t) y = (float)biquad_step(kt, t0, t1, (double)y);
-            if (has_c) y = compress_f32(y);
-            if (has_b) {
-              const double w = biquad_step(kb0, b0, b1, (double)y);
-              if (two) (void)biquad_step(kb1, b2, b3, w);
-            }
-            row[j] = y;
-          } else {
-            double w = biquad_step(kb0, b0, b1, (double)v);
-            if (two) w = biquad_step(kb1, b2, b3, w);
-            row[j] = (float)w;
-          }
-        }
-      }
-    }
-    if (writes) {
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int cc = c0 + 32 * i + mrow;
-        const long long n = (long long)cc * kLc + kSlab * k + 4 * mpart;
-        if (cc < p.nchunk && n + 3 < p.T) {
-          const float* q = tl + (32 * i + mrow) * kSlabRow + 4 * mpart;
-          *reinterpret_cast<float4*>(x + n) = make_float4(q[0], q[1], q[2], q[3]);
-        }
-      }
-    }
   }
-  if (c < p.nchunk) {
-    if (PASS == 0) st[0] = t0, st[1] = t1;
-    if (PASS == 1 && has_b) st[0] = b0, st[1] = b1, st[2] = b2, st[3] = b3;
+}
+
+template <int D>
+__device__ __forceinline__ void matvec(const double* M, const double (&v)[D], double (&out)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) t += M[i * 4 + j] * v[j];
+    out[i] = t;
+  }
+}
+
+// Hand-over between the segments of one stream (different workgroups, possibly on different XCDs, whose L2s are not coherent): the
+// state words travel as 64-bit agent-scope ATOMIC stores / loads (relaxed: they go past the non-coherent cache levels; no release /
+// acquire fence -- on this chip a release writes back the XCD's whole L2, 128 KB of freshly stored samples per workgroup, and made
+// every hop ~15 us).  No flag and no ordering between the words is needed: each word starts as kCarryEmpty and is valid the
+// moment it reads as anything else.  Work items are handed out by an atomic ticket in the order the workgroups START, and segment
+// k of a stream always holds the ticket right after segment k - 1's: whoever is waited for started earlier and is running or
+// done -- no dispatch order is assumed.  The poll is bounded (~1 s; then the error word is raised and a zero state used), so the
+// grid always drains.
+__device__ __forceinline__ double chain_wait(const unsigned long long* word, int* err) {
+  for (int it = 0; it < (1 << 22); ++it) {
+    const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v != kCarryEmpty) return __longlong_as_double((long long)v);
+    __builtin_amdgcn_s_sleep(2);
+  }
+  atomicExch(err, 1);
+  return 0.0;
+}
+__device__ __forceinline__ void chain_post(unsigned long long* word, double v) {
+  __hip_atomic_store(word, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// z: in = zero-state final state of this thread's chunk, out = the chunk's true start state.  Thread 0 is the stream's relay: it
+// folds the waves' totals into the segment's aggregate Z (its final state from a zero start) BEFORE it waits for the previous
+// segment's state s (`prev`, NULL for the first segment), so that what the next segment waits for, M^kFT s + Z, leaves one
+// matrix-vector product after s arrives (`next`); then it leaves s in seg[] for everybody.
+template <int D>
+__device__ __forceinline__ void chain_scan(double (&z)[D], const double (*Mp)[16], double (*wtot)[4], double* seg, int tid,
+                                           const unsigned long long* prev, unsigned long long* next, int* err) {
+  const int lane = tid & 63, wave = tid >> 6;
+  double P[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) P[i] = z[i];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {   // inclusive prefix inside the wave: P_lane = sum_{j <= lane} M^(lane - j) z_j
+    double v[D], t[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      v[i] = __shfl_up(P[i], 1u << k, 64);
+      if (lane < (1 << k)) v[i] = 0.0;
+    }
+    matvec<D>(Mp[k], v, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) P[i] += t[i];
+  }
+  if (lane == 63)
+#pragma unroll
+    for (int i = 0; i < D; ++i) wtot[wave][i] = P[i];
+  __syncthreads();
+  if (tid == 0) {
+    double Z[D], s[D], t[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) Z[i] = 0.0;
+    for (int w = 0; w < kFW; ++w) {   // Z <- M^64 Z + W_w
+      matvec<D>(Mp[6], Z, t);
+#pragma unroll
+      for (int i = 0; i < D; ++i) Z[i] = t[i] + wtot[w][i];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) s[i] = prev ? chain_wait(prev + i, err) : 0.0;
+    matvec<D>(Mp[kFPow - 1], s, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) chain_post(next + i, t[i] + Z[i]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) seg[i] = s[i];
+  }
+  __syncthreads();
+  double C[D];   // state at the start of this wave's first chunk: C_0 = seg, C_(w+1) = M^64 C_w + W_w
+#pragma unroll
+  for (int i = 0; i < D; ++i) C[i] = seg[i];
+  for (int w = 0; w < wave; ++w) {
+    double t[D];
+    matvec<D>(Mp[6], C, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) C[i] = t[i] + wtot[w][i];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {   // M^lane C
+    double t[D];
+    matvec<D>(Mp[k], C, t);
+    const bool bit = (lane >> k) & 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) C[i] = bit ? t[i] : C[i];
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const double e = __shfl_up(P[i], 1u, 64);   // exclusive prefix
+    z[i] = C[i] + (lane == 0 ? 0.0 : e);
+  }
+  __syncthreads();   // every thread has read seg and wtot (the next scan overwrites them)
+}
+
+// one wave: the streams that have a decision -> act[0] = their number, act[1 ..] = their indices (clip * 8 + channel)
+__global__ __launch_bounds__(64) void aug_active_kernel(const mst_aug_clip* dec, int B, int* act) {
+  const int lane = threadIdx.x;
+  int n = 0;
+  for (int s0 = 0; s0 < B * 8; s0 += 64) {
+    const int stream = s0 + lane;
+    bool on = false;
+    if (stream < B * 8) {
+      const mst_aug_stem& d = dec[stream >> 3].stem[(stream & 7) >> 1];
+      on = d.gain != 1.0f || d.tilt != 0 || d.compress != 0 || d.bw_sections > 0;
+    }
+    const unsigned long long m = __ballot(on);
+    if (on) act[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = stream;
+    n += __popcll(m);
+  }
+  if (lane == 0) act[0] = n;
+}
+
+// grid (B * 8 * nseg), kFT threads: one workgroup per (stream, segment), handed out by ticket
+__global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chain_smem[];
+  ChainLds& lds = *reinterpret_cast<ChainLds*>(chain_smem);
+  const int tid = threadIdx.x;
+  if (tid == 0) lds.item = atomicAdd(p.ticket, 1);
+  __syncthreads();
+  const int item = lds.item;
+  if (item >= p.act[0] * p.nseg) return;   // block-uniform: more workgroups than (streams with a decision) x segments
+  const int a = item / p.nseg, sg = item - a * p.nseg, stream = p.act[1 + a];
+  const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
+  const bool has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
+  float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
+  const int T = p.T;
+  const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;   // 16-byte accesses (else four 4-byte ones)
+  const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
+  const Comp kc = comp_of(d);
+  const float gain = d.gain;
+  const bool two = d.bw_sections > 1;
+  ChainCarry* const mine = p.carry + (size_t)a * p.nseg + sg;
+  const ChainCarry* const prev = mine - 1;   // (only dereferenced for sg > 0)
+  // mover mapping: piece i of a segment = 16-byte unit i * kFT + tid -> samples 4 (i kFT + tid) .. + 3 of the segment
+  const int n0 = sg * kFS;
+#pragma unroll
+  for (int i = 0; i < kFL / 4; ++i) {
+    const int u = 4 * (i * kFT + tid);
+    const long long n = (long long)n0 + u;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n + 3 < T) {
+      if (vec) v = *reinterpret_cast<const float4*>(x + n);
+      else v = make_float4(x[n], x[n + 1], x[n + 2], x[n + 3]);
+    } else if (n < T) {
+      v.x = x[n];
+      if (n + 1 < T) v.y = x[n + 1];
+      if (n + 2 < T) v.z = x[n + 2];
+    }
+    float* q = lds.tile + (u / kFL) * kFP + (u % kFL);
+    q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
+  }
+  if (has_t) chain_powers(lds.Mp[0], d.tilt_sos, 1, tid);   // (the loads above are in flight meanwhile)
+  if (has_b) chain_powers(lds.Mp[1], d.bw_sos, d.bw_sections, tid);
+  __syncthreads();
+  float* row = lds.tile + tid * kFP;
+  const int nv = max(0, min(kFL, T - (n0 + tid * kFL)));   // samples of this thread's chunk inside the clip
+  double ts[2] = {0.0, 0.0}, bs[4] = {0.0, 0.0, 0.0, 0.0};
+  // serial walks over the chunk, kFB samples at a time through registers (one LDS round trip per batch, not per sample)
+  auto walk = [&](auto&& f, bool store) __attribute__((always_inline)) {
+    if (nv == kFL) {
+#pragma unroll 1
+      for (int j0 = 0; j0 < kFL; j0 += kFB) {
+        float v[kFB];
+#pragma unroll
+        for (int q = 0; q < kFB; ++q) v[q] = row[j0 + q];
+#pragma unroll
+        for (int q = 0; q < kFB; ++q) v[q] = f(v[q]);
+        if (store) {
+#pragma unroll
+          for (int q = 0; q < kFB; ++q) row[j0 + q] = v[q];
+        }
+      }
+    } else {
+      for (int j = 0; j < nv; ++j) {   // the clip's last, ragged chunk
+        const float o = f(row[j]);
+        if (store) row[j] = o;
+      }
+    }
+  };
+  if (has_t) {   // (1) + (2) of the tilt biquad
+    walk([&](float v) { (void)biquad_step(kt, ts[0], ts[1], (double)(v * gain)); return v; }, false);
+    chain_scan<2>(ts, lds.Mp[0], lds.wtot, lds.seg, tid, sg > 0 ? prev->t : nullptr, mine->t, p.ticket + 1);
+  }
+  // (3) of the tilt biquad, gain, compressor; (1) of the low-pass
+  walk([&](float v) {
+    float y = v * gain;
+    if (has_t) y = (float)biquad_step(kt, ts[0], ts[1], (double)y);
+    if (has_c) y = compress_f32(y, kc);
+    if (has_b) {
+      const double w = biquad_step(kb0, bs[0], bs[1], (double)y);
+      if (two) (void)biquad_step(kb1, bs[2], bs[3], w);
+    }
+    return y;
+  }, true);
+  if (has_b) {
+    if (two) {
+      chain_scan<4>(bs, lds.Mp[1], lds.wtot, lds.seg, tid, sg > 0 ? prev->b : nullptr, mine->b, p.ticket + 1);
+    } else {
+      double b2[2] = {bs[0], bs[1]};
+      chain_scan<2>(b2, lds.Mp[1], lds.wtot, lds.seg, tid, sg > 0 ? prev->b : nullptr, mine->b, p.ticket + 1);
+      bs[0] = b2[0], bs[1] = b2[1];
+    }
+    walk([&](float v) {
+      double w = biquad_step(kb0, bs[0], bs[1], (double)v);
+      if (two) w = biquad_step(kb1, bs[2], bs[3], w);
+      return (float)w;
+    }, true);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kFL / 4; ++i) {
+    const int u = 4 * (i * kFT + tid);
+    const long long n = (long long)n0 + u;
+    const float* q = lds.tile + (u / kFL) * kFP + (u % kFL);
+    if (n + 3 < T) {
+      if (vec) *reinterpret_cast<float4*>(x + n) = make_float4(q[0], q[1], q[2], q[3]);
+      else x[n] = q[0], x[n + 1] = q[1], x[n + 2] = q[2], x[n + 3] = q[3];
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (n + e < T) x[n + e] = q[e];
+    }
   }
 }
 
@@ -443,7 +426,9 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   fill_twiddles<kNfft>(lds.tw, tid, 256);
   __syncthreads();
-  const int b = blockIdx.y, item = blockIdx.x * 4 + wave;
+  // (consecutive windows on one XCD: a window shares half of its samples with each neighbour, so the second read of every sample
+  //  hits that XCD's L2 -- blocks x and x + 8 of a clip share an XCD, mst::xcd_remap hands each XCD a contiguous run)
+  const int b = blockIdx.y, item = mst::xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
   const int mode = p.dec[b].reverb;
   if (mode == 0) return;
   const int nitems = KIND == 0 ? p.NP : p.NX;
@@ -507,6 +492,15 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
 // that the write of step q never touches what step q - 1 reads: one barrier per step).  Global traffic per step: 16 KB per
 // workgroup instead of 128 KB.
 constexpr int kRevWaves = 8, kRevRing = kRevWaves + 1;
+typedef float v2f __attribute__((ext_vector_type(2)));
+// acc + a * w (complex) as two packed FMAs, in the nesting the scalar form had: (acc + (-a.y w.y, a.y w.x)) + (a.x w.x, a.x w.y).
+// Inline asm: hipcc builds the swapped / negated operands of the packed form with v_mov + v_xor (2 moves per FMA).
+__device__ __forceinline__ v2f cmac(v2f acc, v2f a, v2f w) {
+  v2f t, d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));   // (-a.y w.y, a.y w.x) + acc
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(w), "v"(t));                                    // (a.x w.x, a.x w.y) + t
+  return d;
+}
 struct RevLds {
   float2 tw[FftPlan<kNfft>::TW];
   union {
@@ -527,9 +521,13 @@ __global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevP
   const int mode = p.dec[b].reverb;
   if (mode == 0) return;   // block-uniform
   fill_twiddles<kNfft>(lds.tw, tid, kRevWaves * 64);
-  const int jb = p.j0 + blockIdx.x * kRevWaves;   // first output block of this workgroup
+  // Consecutive workgroups of a clip on ONE XCD: workgroup g needs the windows X[8 g - 43 .. 8 g + 7] and all 44 G spectra -- its
+  // neighbour 43 of the same 51 windows and the same G.  Dealt round-robin (the hardware's order), a clip's workgroups on one XCD
+  // are 8 apart and share nothing: every spectrum came from HBM once per workgroup (0.88 GB per step for 0.1 GB of spectra).
+  const int wg = mst::xcd_remap(blockIdx.x, gridDim.x);
+  const int jb = p.j0 + wg * kRevWaves;   // first output block of this workgroup
   const int j = jb + wave;
-  const bool mine = blockIdx.x * kRevWaves + wave < p.nj;
+  const bool mine = wg * kRevWaves + wave < p.nj;
   const float4* Gg = reinterpret_cast<const float4*>(p.G + (size_t)b * p.NP * 1024);
   const float4* Xg = reinterpret_cast<const float4*>(p.X + (size_t)b * p.NX * 1024);
   auto slot = [](int i) { return ((i % kRevRing) + kRevRing) % kRevRing; };
@@ -539,28 +537,42 @@ __global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevP
     const float4 v = (i >= 0 && i < p.NX) ? Xg[(size_t)i * 512 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     reinterpret_cast<float4*>(lds.u.r.X[slot(i)])[tid] = v;
   }
-  float4 gq = Gg[tid], xq = make_float4(0.f, 0.f, 0.f, 0.f);   // G[0]; the new window of step 0 is already in place
-  float2 acc[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = make_float2(0.f, 0.f);
-  for (int q = 0; q < p.NP; ++q) {
-    reinterpret_cast<float4*>(lds.u.r.G[q & 1])[tid] = gq;
-    if (q > 0) reinterpret_cast<float4*>(lds.u.r.X[slot(jb - q)])[tid] = xq;
-    __syncthreads();
-    if (q + 1 < p.NP) {   // next step's two blocks, in flight while this step computes
-      gq = Gg[(size_t)(q + 1) * 512 + tid];
-      const int i = jb - (q + 1);
-      xq = (i >= 0 && i < p.NX) ? Xg[(size_t)i * 512 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // The two 8 KB blocks a step needs (G[q] and the one new window X[jb - q]) are fetched kRevAhead steps ahead into registers: a
+  // step's arithmetic is ~0.3 us, a global load ~1.5 us -- one step of look-ahead left the loop waiting on memory 44 times per
+  // workgroup (the kernel ran 0.36 ms for 0.05 ms of multiply-adds).
+  constexpr int kRevAhead = 4;
+  float4 gq[kRevAhead], xq[kRevAhead];
+  auto issue = [&](int q, float4& gdst, float4& xdst) __attribute__((always_inline)) {
+    if (q < p.NP) {   // block-uniform
+      gdst = Gg[(size_t)q * 512 + tid];
+      const int i = jb - q;
+      xdst = (q > 0 && i >= 0 && i < p.NX) ? Xg[(size_t)i * 512 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);   // (step 0's window is in place)
     }
-    const int i = j - q;
-    if (mine && i >= 0 && i < p.NX) {   // wave-uniform
-      const float2* x = lds.u.r.X[slot(i)] + lane;
-      const float2* g = lds.u.r.G[q & 1] + lane;
+  };
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float2 a = x[r * 64], w = g[r * 64];
-        acc[r].x = fmaf(a.x, w.x, fmaf(-a.y, w.y, acc[r].x));
-        acc[r].y = fmaf(a.x, w.y, fmaf(a.y, w.x, acc[r].y));
+  for (int u = 0; u < kRevAhead; ++u) gq[u] = xq[u] = make_float4(0.f, 0.f, 0.f, 0.f), issue(u, gq[u], xq[u]);
+  v2f acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = v2f{0.f, 0.f};
+  for (int q0 = 0; q0 < p.NP; q0 += kRevAhead) {
+#pragma unroll
+    for (int u = 0; u < kRevAhead; ++u) {
+      const int q = q0 + u;
+      if (q < p.NP) {   // block-uniform
+        reinterpret_cast<float4*>(lds.u.r.G[q & 1])[tid] = gq[u];
+        if (q > 0) reinterpret_cast<float4*>(lds.u.r.X[slot(jb - q)])[tid] = xq[u];
+        __syncthreads();
+        issue(q + kRevAhead, gq[u], xq[u]);
+        const int i = j - q;
+        if (mine && i >= 0 && i < p.NX) {   // wave-uniform
+          const v2f* x = reinterpret_cast<const v2f*>(lds.u.r.X[slot(i)]) + lane;
+          const v2f* g = reinterpret_cast<const v2f*>(lds.u.r.G[q & 1]) + lane;
+          v2f a[16], w[16];   // all 32 reads in flight before the first multiply-add (one LDS round trip per step, not four)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) a[r] = x[r * 64], w[r] = g[r * 64];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = cmac(acc[r], a[r], w[r]);
+        }
       }
     }
   }
@@ -571,7 +583,7 @@ __global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevP
   float2 (&v)[16] = vv[0];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const float2 y = acc[out_reg<kNfft>(in_q<kNfft>(r))];
+    const v2f y = acc[out_reg<kNfft>(in_q<kNfft>(r))];
     v[r] = make_float2(y.x, -y.y);
   }
   FftPlan<kNfft>::run<1>(vv, lds.u.scr[wave], lds.tw, lane);
@@ -645,13 +657,13 @@ __global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevP
 }
 
 struct AugLayout {
-  size_t dec, states, prop, epart, G, X, total;
-  int nchunk, NP, NX, D, j0, nj;
+  size_t dec, act, lb, prop, epart, G, X, total;   // lb: ticket words + carry records (zeroed per launch)
+  size_t lb_bytes;
+  int nseg, NP, NX, D, j0, nj;
 };
 
 AugLayout aug_layout(int B, int T, int L) {
   AugLayout a{};
-  a.nchunk = (T + kLc - 1) / kLc;
   a.NP = L > 0 ? (L + kBlk - 1) / kBlk : 0;
   a.D = L > 0 ? (L - 1) - L / 2 : 0;
   a.j0 = a.D / kBlk;
@@ -665,7 +677,10 @@ AugLayout aug_layout(int B, int T, int L) {
     return at;
   };
   a.dec = take((size_t)B * sizeof(mst_aug_clip));
-  a.states = take((size_t)B * 8 * a.nchunk * 4 * sizeof(double));
+  a.nseg = (T + kFS - 1) / kFS;
+  a.act = take((size_t)(1 + B * 8) * sizeof(int));
+  a.lb_bytes = 64 + (size_t)B * 8 * a.nseg * sizeof(ChainCarry);
+  a.lb = take(a.lb_bytes);
   a.prop = take((size_t)B * 4 * sizeof(float));
   a.G = take((size_t)B * a.NP * 1024 * sizeof(float2));
   a.X = take((size_t)B * a.NX * 1024 * sizeof(float2));
@@ -698,8 +713,14 @@ int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* st
     any_rev = any_rev || decisions[b].reverb != 0;
     MST_REQUIRE(decisions[b].reverb >= 0 && decisions[b].reverb <= 2, "mst_aug_apply: bad reverb flag");
     for (int s = 0; s < 4; ++s)
+    {
       MST_REQUIRE(decisions[b].stem[s].bw_sections >= 0 && decisions[b].stem[s].bw_sections <= 2,
                   "mst_aug_apply: bw_sections must be 0..2");
+      MST_REQUIRE(decisions[b].stem[s].compress >= 0 && decisions[b].stem[s].compress <= 2, "mst_aug_apply: compress must be 0, 1 or 2");
+      MST_REQUIRE(decisions[b].stem[s].compress != 2 || (decisions[b].stem[s].comp_ratio > 0.f && decisions[b].stem[s].comp_threshold_db < 160.f &&
+                                                         decisions[b].stem[s].comp_threshold_db > -160.f),
+                  "mst_aug_apply: compress = 2 needs comp_ratio > 0 and a finite comp_threshold_db");
+    }
   }
   MST_REQUIRE(!any_rev || (reverb_ir && ir_len > 0), "mst_aug_apply: reverb requested but no impulse response");
   const AugLayout L = aug_layout(B, T, any_rev ? ir_len : 0);
@@ -709,26 +730,25 @@ int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* st
   char* ws = reinterpret_cast<char*>(workspace);
   mst_aug_clip* ddec = reinterpret_cast<mst_aug_clip*>(ws + L.dec);
   MST_HIP_CHECK(hipMemcpyAsync(ddec, decisions, (size_t)B * sizeof(mst_aug_clip), hipMemcpyHostToDevice, st));
-  ChainParams cp{stems_inout, ddec, reinterpret_cast<double*>(ws + L.states), T, L.nchunk, clip_stride};
-  bool any_tilt = false, any_bw = false;
+  bool any_chain = false;
   for (int b = 0; b < B; ++b)
-    for (int s = 0; s < 4; ++s)
-      any_tilt = any_tilt || decisions[b].stem[s].tilt != 0, any_bw = any_bw || decisions[b].stem[s].bw_sections > 0;
-  const dim3 cgrid((L.nchunk + 255) / 256, B * 8);
-  // LDS-slab passes (whole-line loads / stores) when every stream is 16-byte aligned; the chunk-walk kernels otherwise
-  const bool slabs = T % 4 == 0 && clip_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(stems_inout) & 15) == 0 &&
-                     !getenv("MST_AUG_CHUNKWALK");
-  if (any_tilt) {
-    if (slabs) hipLaunchKernelGGL((aug_iir_pass_kernel<0>), cgrid, dim3(256), 0, st, cp);
-    else hipLaunchKernelGGL(aug_tilt_zs_kernel, cgrid, dim3(256), 0, st, cp);
-    hipLaunchKernelGGL((aug_scan_kernel<0>), dim3(B * 8), dim3(64), 0, st, cp);
-  }
-  if (slabs) hipLaunchKernelGGL((aug_iir_pass_kernel<1>), cgrid, dim3(256), 0, st, cp);
-  else hipLaunchKernelGGL(aug_tilt_resp_kernel, cgrid, dim3(256), 0, st, cp);
-  if (any_bw) {
-    hipLaunchKernelGGL((aug_scan_kernel<1>), dim3(B * 8), dim3(64), 0, st, cp);
-    if (slabs) hipLaunchKernelGGL((aug_iir_pass_kernel<2>), cgrid, dim3(256), 0, st, cp);
-    else hipLaunchKernelGGL(aug_bw_resp_kernel, cgrid, dim3(256), 0, st, cp);
+    for (int s = 0; s < 4; ++s) {
+      const mst_aug_stem& d = decisions[b].stem[s];
+      any_chain = any_chain || d.gain != 1.0f || d.tilt != 0 || d.compress != 0 || d.bw_sections > 0;
+    }
+  if (any_chain) {
+    int* lb = reinterpret_cast<int*>(ws + L.lb);
+    ChainParams cp{stems_inout, ddec, T, clip_stride, B, L.nseg, reinterpret_cast<int*>(ws + L.act), lb,
+                   reinterpret_cast<ChainCarry*>(ws + L.lb + 64)};
+    static_assert(sizeof(ChainCarry) == 64, "one carry record per 64 bytes");
+    MST_HIP_CHECK(hipMemsetAsync(lb, 0, 64, st));
+    MST_HIP_CHECK(hipMemsetAsync(ws + L.lb + 64, 0xFF, L.lb_bytes - 64, st));   // every carry word = kCarryEmpty
+    hipLaunchKernelGGL(aug_active_kernel, dim3(1), dim3(64), 0, st, ddec, B, cp.act);
+    static unsigned long long chain_attr = 0;   // per-device bit mask: the dynamic-LDS limit belongs to the device
+    if (mst::first_use_on_device(chain_attr))
+      MST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aug_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)sizeof(ChainLds)));
+    hipLaunchKernelGGL(aug_chain_kernel, dim3(B * 8 * L.nseg), dim3(kFT), sizeof(ChainLds), st, cp);
   }
   MST_HIP_CHECK(hipGetLastError());
   if (any_rev) {

@@ -459,9 +459,18 @@ class AudioAugmenter:
         return self._single(audio, lambda c: self._draw_tilt(c.stem[0], {}))
 
     def apply_compression(self, audio, threshold=-20, ratio=4):
-        if threshold != -20 or ratio != 4:
-            raise NotImplementedError("the HIP compressor implements the reference's fixed -20 dB / 4:1 setting")
-        return self._single(audio, lambda c: setattr(c.stem[0], "compress", 1))
+        """reference src/mixing_utils.py:435-447, any threshold (dB) and ratio; the default setting takes the closed form with two
+        square roots (include/mst.h mst_aug_stem.compress = 1), any other one the general power law (compress = 2)."""
+        if not ratio > 0:
+            raise ValueError(f"apply_compression: ratio must be > 0, got {ratio}")
+
+        def fill(c):
+            st = c.stem[0]
+            if threshold == -20 and ratio == 4:
+                st.compress = 1
+            else:
+                st.compress, st.comp_threshold_db, st.comp_ratio = 2, float(threshold), float(ratio)
+        return self._single(audio, fill)
 
     def apply_bandwidth_limit(self, audio):
         return self._single(audio, lambda c: self._draw_bw(c.stem[0], {}))

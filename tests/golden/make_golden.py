@@ -209,6 +209,22 @@ def gen_augment():
     np.savez_compressed(os.path.join(HERE, "augment.npz"), **out)
 
 
+def gen_compress_param():
+    """`apply_compression(audio, threshold, ratio)` of the reference (src/mixing_utils.py:435-447) at NON-default settings -- a
+    separate small fixture (the other fixtures are not regenerated): one mild and one hard setting, on a signal with samples on both
+    sides of either threshold, exact zeros and both signs."""
+    out = {}
+    aug = ref_mu.AudioAugmenter(sample_rate=44100, gain_range=9.0, prob=0.5)
+    x = cases.feature_case("synth1", 33075)[4:6].clone()
+    x[:, :64] = 0.0
+    x[:, 64:128] *= 8.0        # loud samples, well above -6 dB
+    out["input_checksum"] = np.array(float(x.double().abs().sum()))
+    for tag, thr, ratio in (("m12_2", -12.0, 2.0), ("m30_8", -30.0, 8.0), ("m6_1p5", -6.0, 1.5)):
+        out[f"{tag}.params"] = np.array([thr, ratio])
+        out[f"{tag}.samples"] = aug.apply_compression(x, threshold=thr, ratio=ratio).numpy()[:, :8192]
+    np.savez_compressed(os.path.join(HERE, "augment_compress_param.npz"), **out)
+
+
 def gen_song_a():
     """BASELINE configs[0]: two 10 s crops of assets/song_A.wav (the reference's own asset; data, stored as int16),
     fixed pseudo-separation in place of SCNet, reference features + log-mel + embeddings."""

@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     assert C.sizeof(_lib.EncoderConfig) == 9 * 4
     assert C.sizeof(_lib.EncoderWeights) == 24 * C.sizeof(C.c_void_p)
-    assert C.sizeof(_lib.AugStem) == 16 + 18 * 8
+    assert C.sizeof(_lib.AugStem) == 16 + 18 * 8 + 8
     assert C.sizeof(_lib.AugClip) == 4 * C.sizeof(_lib.AugStem) + 8
 
 

@@ -94,6 +94,32 @@ def test_single_effects():
     close(aug.apply_bandwidth_limit(x.cuda()).cpu()[:, :4096], g["bw.out_head"], rtol=1e-5, atol=1e-6)
 
 
+def test_parametric_compressor_matches_the_reference_at_non_default_settings():
+    """`apply_compression(audio, threshold, ratio)` (src/mixing_utils.py:435-447) is parametric in the reference; the fixture
+    holds its output at three non-default settings (tests/golden/make_golden.py::gen_compress_param), on a signal with exact zeros,
+    both signs and samples on both sides of every threshold.  Also against the oracle, and the default setting through the general
+    path equals the closed-form path to 1e-6."""
+    from mst_amd.mixing_utils import AudioAugmenter
+    from oracle import augment as oaug
+    g = np.load(os.path.join(G, "augment_compress_param.npz"))
+    aug = AudioAugmenter()
+    x = cases.feature_case("synth1", 33075)[4:6].clone()
+    x[:, :64] = 0.0
+    x[:, 64:128] *= 8.0
+    assert abs(float(x.double().abs().sum()) - float(g["input_checksum"])) < 1e-9 * float(g["input_checksum"]), "fixture input differs"
+    for tag in ("m12_2", "m30_8", "m6_1p5"):
+        thr, ratio = (float(v) for v in g[f"{tag}.params"])
+        y = aug.apply_compression(x.cuda(), threshold=thr, ratio=ratio).cpu()
+        close(y[:, :8192], g[f"{tag}.samples"], rtol=1e-5, atol=1e-7)
+        close(y, oaug.compress(x, thr, ratio), rtol=1e-5, atol=1e-7)
+        assert torch.equal(y[:, :64], torch.zeros(2, 64)), "sign(0) * anything = 0"
+    a = aug.apply_compression(x.cuda()).cpu()
+    b = aug.apply_compression(x.cuda(), threshold=-20.0, ratio=4.000001).cpu()   # forces the general path at (almost) the default
+    close(b, a, rtol=2e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        aug.apply_compression(x.cuda(), ratio=0)
+
+
 def test_no_decision_is_identity():
     from mst_amd.mixing_utils import AudioAugmenter
     x = cases.feature_case("white", 20000)

@@ -174,6 +174,14 @@ def test_augment_single_effects():
     g = load("augment.npz")
     x = cases.feature_case("synth1", 33075)[4:6]
     close(oaug.compress(x).numpy()[:, :4096], g["compress.samples"], rtol=1e-6, atol=1e-8)
+    # non-default threshold / ratio (the reference's apply_compression is parametric): its own fixture
+    gp = np.load(os.path.join(G, "augment_compress_param.npz"))
+    xp = x.clone()
+    xp[:, :64] = 0.0
+    xp[:, 64:128] *= 8.0
+    for tag in ("m12_2", "m30_8", "m6_1p5"):
+        thr, ratio = (float(v) for v in gp[f"{tag}.params"])
+        close(oaug.compress(xp, thr, ratio).numpy()[:, :8192], gp[f"{tag}.samples"], rtol=1e-6, atol=1e-8)
     torch.manual_seed(123)
     close(oaug.reverb(x, oaug.make_ir(44100)).numpy()[:, :4096], g["reverb.out_head"], rtol=1e-5, atol=1e-6)
 
