@@ -1876,6 +1876,65 @@ void launch_proj(const ProjParams& pj, int ygrid, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// conv1 + BN(eval) + FiLM + ReLU + MaxPool(SUB, 5) for the first-pool heights the MFMA kernels have no tile for
+// (split_size >= 30: SUB = split_size // 10 >= 3, src/model.py:111-117).  Coverage of the reference's geometry, not the fast
+// path: fp32 FMAs on the vector unit, one workgroup = (clip, band, 8 pooled columns) holding the band's 392 x 32 weights and
+// the whole (split + 6) x 46 x 8 input patch in LDS; thread = (output channel, pooled column), walking the pooled rows.
+// Reads the weights from the MFMA fragment table (conv_fragments: [cin / 4][tap][n / 16][lane = 16 (cin % 4) + n % 16]).
+// ------------------------------------------------------------------------------------------
+constexpr int kGenCols = 8, kGenPC = 5 * kGenCols + 6;
+__global__ __launch_bounds__(256) void conv1_generic_kernel(const ConvParams p, int sub) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* wl = gsm;                    // [392 (cin, tap)][32 cout]
+  float* patch = gsm + 392 * 32;      // [8][split + 6][kGenPC]
+  const int tid = threadIdx.x, co = tid & 31, pwl = tid >> 5;
+  const int clip = blockIdx.y / p.nsub, band = blockIdx.y - clip * p.nsub;
+  const int pw0 = blockIdx.x * kGenCols, PR = p.in_rows + 6;
+  constexpr int WBP = ConvGeom<1, 2>::WBP;
+  for (int i = tid; i < 392 * 32; i += 256) {
+    const int k = i >> 5, c = i & 31, ci = k / 49, tap = k - ci * 49;
+    wl[i] = p.wfrag[((size_t)band * 2 + (ci >> 2)) * WBP + ((size_t)tap * 2 + (c >> 4)) * 64 + 16 * (ci & 3) + (c & 15)];
+  }
+  const float* src = p.in + (size_t)clip * p.in_clipstride + (size_t)band * p.in_bandoff;
+  for (int i = tid; i < 8 * PR * kGenPC; i += 256) {
+    const int ci = i / (PR * kGenPC), r = (i / kGenPC) % PR, c = i % kGenPC;
+    const int rin = r - 3, cin = 5 * pw0 + c - 3;
+    patch[i] = (rin >= 0 && rin < p.in_rows && cin >= 0 && cin < p.in_cols) ? src[(size_t)ci * p.in_cstride + (size_t)rin * p.in_cols + cin] : 0.f;
+  }
+  __syncthreads();
+  const int pw = pw0 + pwl;
+  if (pw >= p.out_cols) return;
+  const float2 ac = p.aff[((size_t)clip * p.nsub + band) * 32 + co];
+  float* dst = p.out + (((size_t)clip * p.nsub + band) * 32 + co) * p.out_rows * p.out_cols + pw;
+  for (int ph = 0; ph < p.out_rows; ++ph) {
+    float best = 0.f;   // ReLU: max(0, .) folded into the running maximum
+    for (int r = 0; r < sub; ++r) {
+      float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int ci = 0; ci < 8; ++ci)
+        for (int ky = 0; ky < 7; ++ky) {
+          const float* row = patch + (ci * PR + ph * sub + r + ky) * kGenPC + 5 * pwl;
+          float x[11];
+#pragma unroll
+          for (int j = 0; j < 11; ++j) x[j] = row[j];
+          const float* wk = wl + ((ci * 49 + ky * 7) << 5) + co;
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) {
+            const float w = wk[kx << 5];
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[c] = fmaf(w, x[c + kx], acc[c]);
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const float y = fmaf(ac.x, acc[c], ac.y);
+        best = (y != y) ? y : fmaxf(best, y);   // a NaN stays visible
+      }
+    }
+    dst[(size_t)ph * p.out_cols] = best;
+  }
+}
+
 struct mst_encoder {
   mst_encoder_config cfg{};
   int sub = 0, H1 = 0, FD = 0, C = 0;
@@ -2907,7 +2966,10 @@ int mst_encoder_create(mst_encoder** out, const mst_encoder_config* cfg, const m
               cfg->split_size, cfg->overlap, ns);
   MST_REQUIRE((ns - 1) * cfg->overlap + cfg->split_size <= cfg->n_mels, "mst_encoder_create: sub-bands exceed n_mels");
   const int sub = cfg->split_size / 10 > 1 ? cfg->split_size / 10 : 1;
-  MST_REQUIRE(sub == 1 || sub == 2, "mst_encoder_create: pool height split_size//10 = %d unsupported (1 or 2)", sub);
+  // first-pool heights 1 and 2 run on the MFMA kernels; larger ones on conv1_generic_kernel, whose LDS holds a whole band's patch
+  MST_REQUIRE(sub <= 2 || (size_t)(392 * 32 + 8 * (cfg->split_size + 6) * kGenPC) * sizeof(float) <= 160 * 1024,
+              "mst_encoder_create: split_size=%d (first-pool height %d) exceeds the generic conv1 kernel's LDS (split_size <= 68)",
+              cfg->split_size, sub);
   MST_REQUIRE(cfg->attn_hidden == 256, "mst_encoder_create: attn_hidden must be 256 (got %d)", cfg->attn_hidden);
   MST_REQUIRE(cfg->feature_dim >= 1 && cfg->film_hidden >= 1 && cfg->embed_dim >= 1, "mst_encoder_create: bad dims");
   for (const float* const* q = &w->conv1_w; q <= &w->proj_b; ++q)
@@ -3107,6 +3169,7 @@ static bool conv1_resident_geometry(const mst_encoder* e) {
 int mst_encoder_layout_supported(const mst_encoder* e, int layout) {
   if (!e) return 0;
   if (layout == MST_LOGMEL_REF) return 1;
+  if (e->sub > 2) return 0;   // conv1_generic_kernel reads the reference layout
   if (layout == MST_LOGMEL_CM32) return e->conv1_f16x3 == 0 && conv1_resident_geometry(e);
   if (layout == MST_LOGMEL_CM16) return e->conv1_f16x3 != 0;
   return 0;
@@ -3174,7 +3237,17 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
     const int g = std::min(grid, ns * cp.sets_per_band);
     hipError_t err;
-    if (e->conv1_f16x3) {   // (set_precision admits the f16 modes only for geometries that fit the 2 x 40 tiles)
+    if (e->sub > 2) {   // first-pool heights >= 3: the generic kernel (reference layout, exact fp32)
+      MST_REQUIRE(lay == MST_LOGMEL_REF && e->conv1_f16x3 == 0, "mst_encoder_forward: split_size=%d runs in the reference layout, fp32 only", e->cfg.split_size);
+      const size_t lds = (size_t)(392 * 32 + 8 * (e->cfg.split_size + 6) * kGenPC) * sizeof(float);
+      static unsigned long long attr_gen = 0;   // per-device bit mask: the attribute belongs to the device
+      if (mst::first_use_on_device(attr_gen)) {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_generic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 generic attribute failed: %s", hipGetErrorString(err));
+      }
+      hipLaunchKernelGGL(conv1_generic_kernel, dim3((L.W1 + kGenCols - 1) / kGenCols, B * ns), dim3(256), lds, st, cp, e->sub);
+      err = hipGetLastError();
+    } else if (e->conv1_f16x3) {   // (set_precision admits the f16 modes only for geometries that fit the 2 x 40 tiles)
       using C = CC<1, 2>;
       if (e->sub == 1) {   // 16-mel sub-bands: pool height 1 on the same tiles
         cp.pool_h = 1;
@@ -3374,7 +3447,7 @@ TrainLayout train_layout(const mst_encoder* e, int B, int frames) {
 }  // namespace
 
 size_t mst_encoder_train_workspace_bytes(const mst_encoder* e, int B, int frames) {
-  if (!e || B <= 0 || frames < 20) return 0;
+  if (!e || B <= 0 || frames < 20 || e->sub > 2) return 0;   // (the training kernels cover first-pool heights 1 and 2)
   return train_layout(e, B, frames).total;
 }
 
@@ -3414,6 +3487,7 @@ int mst_encoder_forward_train(const mst_encoder* e, const float* logmel, int fra
 
 int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin, int frames, const float* feats, int B, float* emb,
                                  const mst_encoder_train_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+  MST_REQUIRE(e && e->sub <= 2, "mst_encoder_forward_train: the training kernels cover first-pool heights 1 and 2 (split_size < 30)");
   MST_REQUIRE(e && lin && lin->data && (feats || (taps && taps->film_in)), "mst_encoder_forward_train: NULL argument");
   const int lay = lin->layout;
   MST_REQUIRE(mst_encoder_train_layout_supported(e, lay),

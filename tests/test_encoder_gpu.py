@@ -175,8 +175,44 @@ def test_torch_backend_agrees_and_train_mode_guard():
 def test_unsupported_geometry_fails_loudly():
     from mst_amd import _lib
     from mst_amd.model import MixingStyleEncoder
-    m = MixingStyleEncoder(n_mels=128, split_size=40, overlap=20, feature_dim=64).cuda().eval()  # pool height 4
-    with pytest.raises(_lib.MstError):
+    m = MixingStyleEncoder(n_mels=128, split_size=100, overlap=20, feature_dim=64).cuda().eval()  # a band patch beyond one CU's LDS
+    with pytest.raises(_lib.MstError, match="split_size"):
+        m.hip_encoder()
+
+
+@pytest.mark.parametrize("split,overlap", [(40, 20), (30, 10), (35, 31)])
+def test_first_pool_heights_of_three_and_more(split, overlap):
+    """The reference takes any split_size (src/model.py:111-117: sub = max(1, split_size // 10), MaxPool((sub, 5))); first-pool
+    heights 1 and 2 run on the MFMA kernels, larger ones on conv1_generic_kernel (eval forward, reference layout).  Against the
+    oracle on the same log-mel: pool1 of every band, pool_in, embeddings -- incl. split 35 (H1 = 11: MaxPool floors the last rows
+    away twice), a ragged frame count and B = 3."""
+    from mst_amd.model import MixingStyleEncoder
+    torch.manual_seed(5)
+    m = MixingStyleEncoder(n_mels=128, split_size=split, overlap=overlap, feature_dim=64, embed_dim=256).cuda().eval()
+    with torch.no_grad():   # non-trivial BatchNorm statistics and FiLM gammas
+        for c in m.audio_encoder.subnet_cnns:
+            c.bn1.running_mean.normal_(0, 0.2), c.bn1.running_var.uniform_(0.5, 1.5)
+            c.bn2.running_mean.normal_(0, 0.2), c.bn2.running_var.uniform_(0.5, 1.5)
+    sub = split // 10
+    assert sub >= 3 and m.audio_encoder.freq_dim == (split // sub) // 4
+    T = 256 * 203 + 17
+    x = torch.stack([cases.synth_clip(c, T) for c in range(3)], 0)
+    feats = torch.randn(3, 64, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        lm = m.audio_encoder.mel_preprocessor(omel.tensor_to_stems_dict(x.cuda()))
+        emb, taps = m.hip_encoder().forward(lm, feats.cuda(), taps=True)
+        e_mod = m(omel.tensor_to_stems_dict(x.cuda()), feats.cuda())     # the module's own call negotiates the reference layout
+    assert torch.equal(e_mod, emb)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    otaps = {}
+    oemb = oenc.encoder_from_logmel(sd, lm.cpu(), feats, split, overlap, otaps)
+    for i in range(m.audio_encoder.n_subbands):
+        close(taps["pool1"][:, i].cpu(), otaps[f"pool1_{i}"])
+    close(taps["pool_in"].cpu(), otaps["pool_in"])
+    close(emb.cpu(), oemb)
+    close_elementwise(emb.cpu(), oemb)
+    m.conv1_precision = "f16x3"   # the split-precision modes need the 2-row MFMA tiles and say so
+    with pytest.raises(Exception, match="2-row conv1 tiles"):
         m.hip_encoder()
 
 
