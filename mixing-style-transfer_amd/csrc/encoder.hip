@@ -189,6 +189,7 @@ struct ConvParams {
   // conv1_resident_kernel<2> only: 1 = MaxPool2d((1, 5)) on its 2 x 40 tiles (16-mel sub-bands: split // 10 == 1) -- the
   // lane's 10 accumulator positions are two 1 x 5 windows, one per tile row, instead of one 2 x 5 window; 0 / 2 = (2, 5)
   int pool_h;
+  int clip_major;   // conv1_resident_kernel: order of the sets, see its decode()
   // f16 training (mode 1): the raw output is STORED as float16 times the band's power-of-two scale y_scale[band][2] = (s, 1/s)
   // (yraw16, same accumulator-order layout) -- the conv outputs of the reference's autocast step are half tensors too --
   // and the batch statistics are those of the stored values.  NULL: fp32 yraw.
@@ -592,17 +593,33 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 
   const int G = gridDim.x;
   const int wg = mst::xcd_remap(blockIdx.x, G);
-  const int total_sets = p.nsub * p.sets_per_band;
+  // Order of the sets.  Band-major (clip_major = 0; the training forward: the batch statistics are flushed at every band change,
+  // so a workgroup should see as few as possible): sets_per_band sets per band, the clips' tiles concatenated inside it.
+  // Clip-major (clip_major = 1; the eval forward): sets_per_band counts the sets of ONE (clip, band) and the 11 bands of a clip
+  // follow each other -- neighbouring sub-bands share half of their mel rows, and with the bands of a clip on neighbouring
+  // workgroups (one XCD, a few tiles apart in time) the second read of a row hits that XCD's L2 instead of coming from HBM a
+  // whole band pass (0.5 GB of other traffic) later.  A workgroup's run then crosses ~3 band changes (50 KB of weights each).
+  const int total_sets = (p.clip_major ? p.B : 1) * p.nsub * p.sets_per_band;
   const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
   const int tpb = p.tiles_r * p.tiles_c;
 
   auto decode = [&](int s) __attribute__((always_inline)) {
     Tile t;
-    t.band = min(s / p.sets_per_band, p.nsub - 1);
-    const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
-    t.valid = (s < s_end) && idx < p.B * tpb;
-    t.clip = t.valid ? idx / tpb : 0;
-    const int ti = t.valid ? idx - t.clip * tpb : 0;
+    int ti;
+    if (p.clip_major) {
+      const int cb = min(s / p.sets_per_band, p.B * p.nsub - 1);
+      const int idx = (s - cb * p.sets_per_band) * kConvWaves + wave;
+      t.clip = cb / p.nsub;
+      t.band = cb - t.clip * p.nsub;
+      t.valid = (s < s_end) && idx < tpb;
+      ti = t.valid ? idx : 0;
+    } else {
+      t.band = min(s / p.sets_per_band, p.nsub - 1);
+      const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
+      t.valid = (s < s_end) && idx < p.B * tpb;
+      t.clip = t.valid ? idx / tpb : 0;
+      ti = t.valid ? idx - t.clip * tpb : 0;
+    }
     t.tc = ti / p.tiles_r;
     t.tr = ti - t.tc * p.tiles_r;
     return t;
@@ -917,17 +934,33 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
 
   const int G = gridDim.x;
   const int wg = mst::xcd_remap(blockIdx.x, G);
-  const int total_sets = p.nsub * p.sets_per_band;
+  // Order of the sets.  Band-major (clip_major = 0; the training forward: the batch statistics are flushed at every band change,
+  // so a workgroup should see as few as possible): sets_per_band sets per band, the clips' tiles concatenated inside it.
+  // Clip-major (clip_major = 1; the eval forward): sets_per_band counts the sets of ONE (clip, band) and the 11 bands of a clip
+  // follow each other -- neighbouring sub-bands share half of their mel rows, and with the bands of a clip on neighbouring
+  // workgroups (one XCD, a few tiles apart in time) the second read of a row hits that XCD's L2 instead of coming from HBM a
+  // whole band pass (0.5 GB of other traffic) later.  A workgroup's run then crosses ~3 band changes (50 KB of weights each).
+  const int total_sets = (p.clip_major ? p.B : 1) * p.nsub * p.sets_per_band;
   const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
   const int tpb = p.tiles_r * p.tiles_c;
 
   auto decode = [&](int s) __attribute__((always_inline)) {
     Tile t;
-    t.band = min(s / p.sets_per_band, p.nsub - 1);
-    const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
-    t.valid = (s < s_end) && idx < p.B * tpb;
-    t.clip = t.valid ? idx / tpb : 0;
-    const int ti = t.valid ? idx - t.clip * tpb : 0;
+    int ti;
+    if (p.clip_major) {
+      const int cb = min(s / p.sets_per_band, p.B * p.nsub - 1);
+      const int idx = (s - cb * p.sets_per_band) * kConvWaves + wave;
+      t.clip = cb / p.nsub;
+      t.band = cb - t.clip * p.nsub;
+      t.valid = (s < s_end) && idx < tpb;
+      ti = t.valid ? idx : 0;
+    } else {
+      t.band = min(s / p.sets_per_band, p.nsub - 1);
+      const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
+      t.valid = (s < s_end) && idx < p.B * tpb;
+      t.clip = t.valid ? idx / tpb : 0;
+      ti = t.valid ? idx - t.clip * tpb : 0;
+    }
     t.tc = ti / p.tiles_r;
     t.tr = ti - t.tc * p.tiles_r;
     return t;
@@ -3314,7 +3347,11 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
         cp.tiles_c = (L.W1 + 7) / 8;
         cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
       }
-      const int g = std::min(grid, ns * cp.sets_per_band);
+      if (!getenv("MST_CONV1_BAND_MAJOR")) {   // eval forward: the bands of a clip next to each other (decode() of the kernel)
+        cp.clip_major = 1;
+        cp.sets_per_band = (cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+      }
+      const int g = std::min(grid, (cp.clip_major ? B : 1) * ns * cp.sets_per_band);
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {

@@ -1007,10 +1007,33 @@ def test_song_a_real_music_end_to_end():
         model.conv1_precision = "fp32"
     close(emb.cpu(), g["embedding"], 2e-4)
     close(emb16.cpu(), g["embedding"], 2e-4)
-    # element-wise on real music: the log-mel of low-passed stems carries fp32 FFT noise in its quiet bins (check_logmel), which
-    # a handful of embedding elements inherit -- counted and bounded here (measured: 20 of 1536 beyond 1e-4, worst 2.9e-4)
-    close_elementwise(emb.cpu(), g["embedding"], max_miss=48, hard=5e-4, name="song_A embedding fp32 kernels vs reference")
-    close_elementwise(emb16.cpu(), g["embedding"], max_miss=48, hard=5e-4, name="song_A embedding f16x3-all vs reference")
+    # Element-wise on real music the literal 1e-4 cannot be asked of ANY fp32 implementation: the log-mel of low-passed stems carries
+    # fp32 FFT noise in its quiet bins (check_logmel) and a handful of embedding elements inherit it.  The allowance is derived from
+    # the data, not a constant: the same encoder evaluated in FLOAT64 on the float64 log-mel of the same clips is the yardstick,
+    # and the reference's own fp32 embedding (the golden) is measured against it first -- here 27 of 1536 elements are beyond 1e-4,
+    # the worst by 2.8e-4.  The kernels may miss the float64 result on at most 1.25 x as many elements (+ 4) and by at most 2 x
+    # as much as the reference's own arithmetic does.
+    from test_melfeat_gpu import fft_noise_unit
+    _, lm64 = fft_noise_unit(x)
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+    e64 = oenc.encoder_from_logmel(sd64, lm64, torch.from_numpy(g["features"]).double(), cases.CFG_DEFAULT["split_size"],
+                                   cases.CFG_DEFAULT["overlap"])
+    floor = 1e-2 * e64.abs().amax(dim=1, keepdim=True)
+
+    def vs64(e):
+        rel = (e.double() - e64).abs() / torch.maximum(e64.abs(), floor)
+        return int((rel > 1e-4).sum()), float(rel.max())
+    miss_ref, worst_ref = vs64(torch.from_numpy(g["embedding"]))
+    parity.note("song_A embedding: the reference's own fp32 output vs the float64 encoder", beyond_1e_4=miss_ref, worst=worst_ref,
+                elements=int(e64.numel()))
+    assert worst_ref < 1e-3, "the float64 yardstick and the reference golden disagree: fixture or oracle broken"
+    for name, e in (("fp32 kernels", emb), ("f16x3-all", emb16)):
+        miss, worst = vs64(e.cpu())
+        parity.note(f"song_A embedding: {name} vs the float64 encoder", beyond_1e_4=miss, worst=worst,
+                    allowed_beyond=int(1.25 * miss_ref + 4), allowed_worst=2.0 * max(worst_ref, 1e-4))
+        parity.record(f"song_A embedding {name} vs reference [element-wise]", e.cpu(), g["embedding"])
+        assert miss <= 1.25 * miss_ref + 4, f"{name}: {miss} elements beyond 1e-4 of the float64 result; the reference's own fp32: {miss_ref}"
+        assert worst <= 2.0 * max(worst_ref, 1e-4), f"{name}: worst element {worst:.2e} vs the reference's own {worst_ref:.2e}"
 
 
 def test_retrieval_validation_on_hip_path(tmp_path):

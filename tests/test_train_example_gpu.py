@@ -19,7 +19,7 @@ def test_example_training_loop_runs(tmp_path, precision):
                       "--clip-seconds", "1.0", "--batch-size", "6", "--steps", "12", "--lr", "3e-4", "--train-precision", precision])
     assert len(losses) == 12 and all(l == l and l < 10 for l in losses)
     # No "the loss must go down" here: 12 steps of 12 toy clips with Dropout 0.3 sit inside the loss's batch-to-batch noise (+-0.2
-    # around ln 12; measured over 60 steps with either small-nets backend, scripts/probe_example.sh) -- the earlier form of this test
+    # around ln 12; measured over 60 steps with either small-nets backend, examples/train_contrastive.py --steps 60, round 3) -- the earlier form of this test
     # passed or failed with the RNG stream.  That the step DESCENDS is checked deterministically in
     # tests/test_head_gpu.py::test_training_step_is_a_descent_direction.
     assert abs(sum(losses[-3:]) / 3 - sum(losses[:3]) / 3) < 0.5, losses   # (no divergence)
