@@ -564,6 +564,14 @@ def main():
                     tj = json.load(open(tp))   # kernel at the same shapes is quoted, with its source
                     traffic = tj.get("conv1", {}).get("hbm_bytes_per_launch")
                     traffic_src = f"profiles/traffic.json ({tj.get('passes', 'rocprofv3 --pmc')}); not measured by this run"
+                    sa = tj.get("stage_a", {})
+                    if sa:   # what limits stage A (it is issue / latency-bound, not HBM-bound): counters of the same kernel at the same shapes
+                        roof["stage_a_traffic"] = sa.get("hbm_bytes_per_launch")
+                        iss = sa.get("issue", {})
+                        roof["stage_a_valu_frac"] = iss.get("valu_busy_frac")   # share of SIMD time the vector ALUs execute
+                        roof["stage_a_lds_frac"] = iss.get("lds_busy_frac")     # share of time the CUs' LDS pipes are busy
+                        roof["stage_a_wave_wait_frac"] = iss.get("wave_wait_frac")
+                        roof["stage_a_counters_source"] = iss.get("source")
                 except Exception:
                     traffic = None
         else:   # BASELINE configs[1]: stage B on PyTorch-ROCm library kernels -- no per-kernel events, whole-stage rate
