@@ -595,24 +595,29 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   const int wg = mst::xcd_remap(blockIdx.x, G);
   // Order of the sets.  Band-major (clip_major = 0; the training forward: the batch statistics are flushed at every band change,
   // so a workgroup should see as few as possible): sets_per_band sets per band, the clips' tiles concatenated inside it.
-  // Clip-major (clip_major = 1; the eval forward): sets_per_band counts the sets of ONE (clip, band) and the 11 bands of a clip
-  // follow each other -- neighbouring sub-bands share half of their mel rows, and with the bands of a clip on neighbouring
-  // workgroups (one XCD, a few tiles apart in time) the second read of a row hits that XCD's L2 instead of coming from HBM a
-  // whole band pass (0.5 GB of other traffic) later.  A workgroup's run then crosses ~3 band changes (50 KB of weights each).
-  const int total_sets = (p.clip_major ? p.B : 1) * p.nsub * p.sets_per_band;
+  // Clip-group-major (clip_major = k > 0; the eval forward): the clips are taken k at a time, and inside a group the bands follow
+  // each other ([group][band][clip of the group][tile]; sets_per_band counts the sets of ONE (group, band)).  Measured on 72
+  // clips (FETCH_SIZE x 2 per launch, kernel time equal within +-0.5 % for all of them): band-major 1.93 GB, k = 4 1.77 GB,
+  // k = 1 1.11 GB = 72 x 11 patches of 26 mel rows, i.e. every (clip, band) patch fetched exactly once; the sub-bands' shared
+  // rows (each mel row sits in two bands: 0.51 GB algorithmic) are never in L2 long enough in any order -- a workgroup meets them
+  // again a whole (clip, band) later.  k = 1 pads the 430 tiles of a (clip, band) to 54 sets (0.5 % empty wave slots).
+  const int total_sets = (p.clip_major ? (p.B + p.clip_major - 1) / p.clip_major : 1) * p.nsub * p.sets_per_band;
   const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
   const int tpb = p.tiles_r * p.tiles_c;
 
   auto decode = [&](int s) __attribute__((always_inline)) {
     Tile t;
     int ti;
-    if (p.clip_major) {
-      const int cb = min(s / p.sets_per_band, p.B * p.nsub - 1);
-      const int idx = (s - cb * p.sets_per_band) * kConvWaves + wave;
-      t.clip = cb / p.nsub;
-      t.band = cb - t.clip * p.nsub;
-      t.valid = (s < s_end) && idx < tpb;
-      ti = t.valid ? idx : 0;
+    if (p.clip_major) {   // groups of clip_major clips: [group][band][clip of the group][tile]
+      const int ngrp = (p.B + p.clip_major - 1) / p.clip_major;
+      const int gb = min(s / p.sets_per_band, ngrp * p.nsub - 1);
+      const int idx = (s - gb * p.sets_per_band) * kConvWaves + wave;
+      const int grp = gb / p.nsub, c0 = grp * p.clip_major;
+      t.band = gb - grp * p.nsub;
+      t.valid = (s < s_end) && idx < min(p.clip_major, p.B - c0) * tpb;
+      const int cl = t.valid ? idx / tpb : 0;
+      t.clip = c0 + cl;
+      ti = t.valid ? idx - cl * tpb : 0;
     } else {
       t.band = min(s / p.sets_per_band, p.nsub - 1);
       const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
@@ -936,24 +941,29 @@ __global__ __launch_bounds__(kConvThreads) void conv1_f16x3_kernel(const ConvPar
   const int wg = mst::xcd_remap(blockIdx.x, G);
   // Order of the sets.  Band-major (clip_major = 0; the training forward: the batch statistics are flushed at every band change,
   // so a workgroup should see as few as possible): sets_per_band sets per band, the clips' tiles concatenated inside it.
-  // Clip-major (clip_major = 1; the eval forward): sets_per_band counts the sets of ONE (clip, band) and the 11 bands of a clip
-  // follow each other -- neighbouring sub-bands share half of their mel rows, and with the bands of a clip on neighbouring
-  // workgroups (one XCD, a few tiles apart in time) the second read of a row hits that XCD's L2 instead of coming from HBM a
-  // whole band pass (0.5 GB of other traffic) later.  A workgroup's run then crosses ~3 band changes (50 KB of weights each).
-  const int total_sets = (p.clip_major ? p.B : 1) * p.nsub * p.sets_per_band;
+  // Clip-group-major (clip_major = k > 0; the eval forward): the clips are taken k at a time, and inside a group the bands follow
+  // each other ([group][band][clip of the group][tile]; sets_per_band counts the sets of ONE (group, band)).  Measured on 72
+  // clips (FETCH_SIZE x 2 per launch, kernel time equal within +-0.5 % for all of them): band-major 1.93 GB, k = 4 1.77 GB,
+  // k = 1 1.11 GB = 72 x 11 patches of 26 mel rows, i.e. every (clip, band) patch fetched exactly once; the sub-bands' shared
+  // rows (each mel row sits in two bands: 0.51 GB algorithmic) are never in L2 long enough in any order -- a workgroup meets them
+  // again a whole (clip, band) later.  k = 1 pads the 430 tiles of a (clip, band) to 54 sets (0.5 % empty wave slots).
+  const int total_sets = (p.clip_major ? (p.B + p.clip_major - 1) / p.clip_major : 1) * p.nsub * p.sets_per_band;
   const int s_begin = (int)((long long)wg * total_sets / G), s_end = (int)((long long)(wg + 1) * total_sets / G);
   const int tpb = p.tiles_r * p.tiles_c;
 
   auto decode = [&](int s) __attribute__((always_inline)) {
     Tile t;
     int ti;
-    if (p.clip_major) {
-      const int cb = min(s / p.sets_per_band, p.B * p.nsub - 1);
-      const int idx = (s - cb * p.sets_per_band) * kConvWaves + wave;
-      t.clip = cb / p.nsub;
-      t.band = cb - t.clip * p.nsub;
-      t.valid = (s < s_end) && idx < tpb;
-      ti = t.valid ? idx : 0;
+    if (p.clip_major) {   // groups of clip_major clips: [group][band][clip of the group][tile]
+      const int ngrp = (p.B + p.clip_major - 1) / p.clip_major;
+      const int gb = min(s / p.sets_per_band, ngrp * p.nsub - 1);
+      const int idx = (s - gb * p.sets_per_band) * kConvWaves + wave;
+      const int grp = gb / p.nsub, c0 = grp * p.clip_major;
+      t.band = gb - grp * p.nsub;
+      t.valid = (s < s_end) && idx < min(p.clip_major, p.B - c0) * tpb;
+      const int cl = t.valid ? idx / tpb : 0;
+      t.clip = c0 + cl;
+      ti = t.valid ? idx - cl * tpb : 0;
     } else {
       t.band = min(s / p.sets_per_band, p.nsub - 1);
       const int idx = (s - t.band * p.sets_per_band) * kConvWaves + wave;
@@ -3347,11 +3357,12 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
         cp.tiles_c = (L.W1 + 7) / 8;
         cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
       }
-      if (!getenv("MST_CONV1_BAND_MAJOR")) {   // eval forward: the bands of a clip next to each other (decode() of the kernel)
-        cp.clip_major = 1;
-        cp.sets_per_band = (cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+      if (!getenv("MST_CONV1_BAND_MAJOR")) {   // eval forward: the bands of a clip group next to each other (decode() of the kernel)
+        const char* env = getenv("MST_CONV1_CLIP_GROUP");
+        cp.clip_major = std::max(1, std::min(B, env ? atoi(env) : 1));   // 1: every (clip, band) patch comes from HBM exactly once (measured)
+        cp.sets_per_band = (cp.clip_major * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
       }
-      const int g = std::min(grid, (cp.clip_major ? B : 1) * ns * cp.sets_per_band);
+      const int g = std::min(grid, (cp.clip_major ? (B + cp.clip_major - 1) / cp.clip_major : 1) * ns * cp.sets_per_band);
       constexpr size_t lds = (size_t)(2 * 49 * C::NT * 64 + kConvWaves * 8 * C::PR * C::PC) * sizeof(float);
       static unsigned long long attr_set = 0;   // per-device bit mask: the attribute belongs to the device
       if (mst::first_use_on_device(attr_set)) {
