@@ -93,6 +93,39 @@ def default_stem_loader(path):
         raise RuntimeError(f"cannot decode {path}: torchaudio is not installed; pass stem_loader= or use PCM .wav stems")
 
 
+def resample_sinc_hann(audio, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """`torchaudio.transforms.Resample(orig_freq, new_freq)(audio)` -- what the reference calls when a stem's rate differs from the
+    dataset's (src/data.py:174-176, :425-427) -- restated from torchaudio's published algorithm for the case that torchaudio is not
+    installed (torchaudio/functional/functional.py `_get_sinc_resample_kernel` / `_apply_sinc_resample_kernel`, defaults:
+    `sinc_interp_hann`, lowpass_filter_width 6, rolloff 0.99): a bank of new_freq/gcd Hann-windowed sinc filters at
+    0.99 x the lower Nyquist, evaluated in float64 and rounded to float32, applied as one strided conv1d; output length
+    ceil(new * n / orig).  Host-side (a Dataset worker's job); pinned to the algorithm, not to a torchaudio build (absent here)."""
+    import math
+
+    import torch.nn.functional as F
+    orig_freq, new_freq = int(orig_freq), int(new_freq)
+    if orig_freq == new_freq:
+        return audio
+    g = math.gcd(orig_freq, new_freq)
+    orig, new = orig_freq // g, new_freq // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+    kernels = kernels.to(torch.float32)
+    shape = audio.shape
+    wav = audio.reshape(-1, shape[-1]).float()
+    n = wav.shape[-1]
+    wav = F.pad(wav, (width, width + orig))
+    out = F.conv1d(wav[:, None], kernels, stride=orig).transpose(1, 2).reshape(wav.shape[0], -1)
+    out = out[..., :int(math.ceil(new * n / orig))]
+    return out.reshape(shape[:-1] + out.shape[-1:])
+
+
 def _clip_features(ds, clip_stems):
     """Features slot of one clip: the real vector (`compute_features=True`, needs a usable GPU context in this
     process) or the deferred placeholder row the model fills in on the device (default; "auto" is an alias)."""
@@ -139,7 +172,7 @@ class FMABaselineDataset(Dataset):
                 import torchaudio
                 audio = torchaudio.transforms.Resample(sr, self.sr)(audio)
             except ImportError:
-                raise RuntimeError(f"{stem_path}: sample rate {sr} != {self.sr} and torchaudio (Resample) is not installed")
+                audio = resample_sinc_hann(audio, sr, self.sr)   # torchaudio's published algorithm, restated
         if audio.shape[0] == 1:
             audio = audio.repeat(2, 1)
         elif audio.shape[0] > 2:
@@ -268,9 +301,13 @@ class StyleTransferDataset(Dataset):
                 if not os.path.exists(path):
                     raise FileNotFoundError(f"Missing stem: {path}")
                 audio, sr = self.stem_loader(path)
-                if sr != self.sr:
-                    raise RuntimeError(f"{path}: sample rate {sr} != {self.sr} (resampling needs torchaudio)")
                 audio = audio.float()
+                if sr != self.sr:   # src/data.py:425-427
+                    try:
+                        import torchaudio
+                        audio = torchaudio.transforms.Resample(sr, self.sr)(audio)
+                    except ImportError:
+                        audio = resample_sinc_hann(audio, sr, self.sr)
                 stems[name] = audio.repeat(2, 1) if audio.shape[0] == 1 else audio
             return stems
         audio, sr = self.audio_loader(self.audio_files[idx])
