@@ -25,7 +25,7 @@ def _bench(args, **env):
 
 
 def test_contract_line_hip_encoder():
-    out = _bench(SMALL)
+    out = _bench(SMALL + ["--verify-b1"])
     assert out["n_gpus"] == 1 and out["world"] == 1 and out["unit"] == "triplets/s" and out["value"] > 0
     rf = out["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "stage_a_hbm_frac", "stage_b_tflops",
@@ -37,6 +37,7 @@ def test_contract_line_hip_encoder():
     # the timed workload is checked after timing: every clip bit-equal to its B = 1 run (no oracle here: --no-cpu-baseline)
     v = out["config"]["verified"]
     assert v["ok"] and v["batch_independence"]["bit_equal"] == v["clips"] == out["config"]["clips_per_gpu"]
+    assert v["batch_independence"]["re_runs"] == ["reversed", "rotated by 29", "every clip alone (B = 1)"]
     assert out["ms_per_step_median"] > 0
     for row in out["alt"]:
         assert "error" not in row, row
