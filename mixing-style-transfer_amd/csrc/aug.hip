@@ -3,8 +3,9 @@
 // :435-447, apply_bandwidth_limit :449-456, apply_reverb :458-479.  All random decisions (coins, gain, cutoff,
 // impulse response) are drawn by the host in the reference's order and arrive in `mst_aug_clip` / `reverb_ir`.
 //
-//   aug_chain_kernel   x*gain -> biquad (tilt) -> compressor -> 1-2 biquads (low-pass): one workgroup per channel, segments of
-//                      32 768 samples resident in LDS, float64 block-parallel IIR inside a segment (see the kernel's comment);
+//   aug_chain_kernel   x*gain -> biquad (tilt) -> compressor -> 1-2 biquads (low-pass): one workgroup per (channel, segment) of
+//                      16 384 samples resident in LDS, float64 block-parallel IIR inside a segment, decoupled look-back between a
+//                      stream's segments (see the kernel's comment);
 //                      one read and one write of every channel that has a decision.  scipy.signal.sosfilt is a sequential
 //                      fp64 DF2T recurrence; rounded to fp32 exactly where the reference calls `.float()`.
 //   aug_energy_kernel  per-stem mean square for the reverb redistribution weights (:410-416).
@@ -25,7 +26,8 @@ using namespace mstfft;
 constexpr int kBlk = 512;     // overlap-save block (FFT size 1024)
 constexpr int kNfft = 1024;
 
-struct ChainCarry {           // what segment k of a stream hands to segment k + 1: the filter states after its last sample.  Every word
+struct ChainCarry {           // what segment k of a stream publishes: its AGGREGATES Z (the filter states after its last sample when started
+                              // from rest), from which every later segment folds its own start state (chain_scan).  Every word
   unsigned long long t[2], b[4], pad_[2];   // starts as kCarryEmpty and is written ONCE, with one 64-bit agent-scope atomic store
 };
 constexpr unsigned long long kCarryEmpty = ~0ull;   // (all ones: a NaN pattern no arithmetic produces; hipMemset 0xFF)
@@ -36,6 +38,7 @@ struct ChainParams {
   long long clip_stride;     // floats between clips (8 * T when packed)
   int B, nseg;
   int* act;                  // [1 + B * 8]: number of streams with a decision, then their indices (aug_active_kernel)
+  double* pow;               // [B * 8][2 filters][kFPow][16]: powers M^(2^k) of the chunk transitions (aug_powers_kernel)
   int* ticket;               // [2]: work-item counter, error word (zeroed per launch)
   ChainCarry* carry;         // [B * 8][nseg] (zeroed per launch)
 };
@@ -68,23 +71,25 @@ __device__ __forceinline__ Comp comp_of(const mst_aug_stem& d) {
 }
 
 // ---- the IIR chain  x * gain -> [tilt biquad] -> [compressor] -> [1-2 low-pass biquads]  (mixing_utils.py:389-456) in ONE kernel.
-// scipy.signal.sosfilt is a sequential float64 DF2T recurrence over the whole channel.  Here ONE WORKGROUP owns one channel
-// ("stream") and walks it in segments of 32 768 samples that live in LDS: the segment is read from HBM once (whole 128-byte
+// scipy.signal.sosfilt is a sequential float64 DF2T recurrence over the whole channel.  Here a channel ("stream") is cut into
+// segments of 16 384 samples and ONE WORKGROUP owns one segment, which lives in LDS: it is read from HBM once (whole 128-byte
 // lines), every pass over it reads and writes LDS, and it is written back once -- the chain moves its algorithmic bytes, one
 // read and one write of every stream that has a decision (the three-launch form of round 3 read a filtered stream three times
-// and wrote it twice).  Inside a segment the recurrences are block-parallel, exactly as before: a thread owns a chunk of 64
+// and wrote it twice).  Inside a segment the recurrences are block-parallel, exactly as before: a thread owns a chunk of 32
 // consecutive samples;
 //   (1) zero-state pass: the chunk's final filter state when started from rest (z_c);
-//   (2) scan: start state of every chunk, s_c = M^c s_seg + sum_{j<c} M^(c-1-j) z_j with M = A^64 (the homogeneous transition
-//       of a chunk), as a doubling prefix inside each wave (shared powers M^1 .. M^32 in LDS), a serial carry over the 8 waves
-//       (M^64) and a lane-dependent power M^lane of the wave's carry;  the state after the last chunk seeds the next segment;
+//   (2) scan: start state of every chunk, s_c = M^c s_seg + sum_{j<c} M^(c-1-j) z_j with M = A^32 (the homogeneous transition
+//       of a chunk; the powers M^(2^k) come from aug_powers_kernel, once per stream), as a doubling prefix inside each wave, a
+//       serial carry over the 8 waves (M^64) and a lane-dependent power M^lane of the wave's carry; s_seg, the state at the
+//       segment's start, comes from the EARLIER SEGMENTS' aggregates (decoupled look-back across workgroups: chain_scan);
 //   (3) response pass: every chunk re-run from its true start state -- the reference's arithmetic sample for sample (float64
 //       DF2T, sosfilt's section order, `.float()` after each filter); only the chunk start states are obtained differently.
 // The tilt response pass also applies gain and compressor and runs the low-pass zero-state pass on the values it has just
-// produced.  The next segment's samples are loaded into registers while this one is processed.
+// produced.  66 KB of LDS per workgroup: two workgroups per CU cover each other's loads, barriers and look-back polls
+// (measured: 512 threads x 32 samples 0.47 ms with every effect on every one of 192 streams; x 64 samples 0.56; 256 x 32 0.45).
 #ifndef MST_AUG_FT
 #define MST_AUG_FT 512
-#define MST_AUG_FL 64
+#define MST_AUG_FL 32
 #define MST_AUG_FB 16
 #endif
 constexpr int kFT = MST_AUG_FT, kFL = MST_AUG_FL, kFS = kFT * kFL, kFP = kFL + 1;   // threads, samples per chunk, samples per segment, LDS row pitch
@@ -107,7 +112,8 @@ struct ChainLds {
   float tile[kFT * kFP];
   double Mp[2][kFPow][16]; // [filter: 0 tilt, 1 low-pass][k][4 x 4]: M^(2^k), k = 0 .. log2(kFT), zero outside the D x D block
   double wtot[kFW][4];     // inclusive prefix of every wave's last lane
-  double seg[4];           // state at the start of this segment (from the previous segment's workgroup)
+  double seg[4];           // state at the start of this segment
+  double zin[kFT];         // the earlier segments' aggregates, [segment][D]
   int item;                // this workgroup's ticket
 };
 
@@ -138,6 +144,21 @@ __device__ __forceinline__ void chain_powers(double (*Mp)[16], const double* sos
   }
 }
 
+// one wave per stream: the powers of both filters' chunk transitions, ONCE per stream (every segment workgroup of the stream
+// reads them: 2.8 KB) instead of once per segment workgroup (64 dependent recurrence steps + 10 squarings behind barriers)
+__global__ __launch_bounds__(64) void aug_powers_kernel(const mst_aug_clip* dec, double* pow) {
+  __shared__ double Mp[kFPow][16];
+  const int stream = blockIdx.x, tid = threadIdx.x;
+  const mst_aug_stem& d = dec[stream >> 3].stem[(stream & 7) >> 1];
+  for (int f = 0; f < 2; ++f) {
+    const int NS = f == 0 ? (d.tilt != 0 ? 1 : 0) : d.bw_sections;
+    if (NS == 0) continue;   // block-uniform
+    chain_powers(Mp, f == 0 ? d.tilt_sos : d.bw_sos, NS, tid);
+    for (int i = tid; i < kFPow * 16; i += 64) pow[((size_t)stream * 2 + f) * (kFPow * 16) + i] = Mp[i >> 4][i & 15];
+    __syncthreads();
+  }
+}
+
 template <int D>
 __device__ __forceinline__ void matvec(const double* M, const double (&v)[D], double (&out)[D]) {
 #pragma unroll
@@ -153,10 +174,10 @@ __device__ __forceinline__ void matvec(const double* M, const double (&v)[D], do
 // state words travel as 64-bit agent-scope ATOMIC stores / loads (relaxed: they go past the non-coherent cache levels; no release /
 // acquire fence -- on this chip a release writes back the XCD's whole L2, 128 KB of freshly stored samples per workgroup, and made
 // every hop ~15 us).  No flag and no ordering between the words is needed: each word starts as kCarryEmpty and is valid the
-// moment it reads as anything else.  Work items are handed out by an atomic ticket in the order the workgroups START, and segment
-// k of a stream always holds the ticket right after segment k - 1's: whoever is waited for started earlier and is running or
-// done -- no dispatch order is assumed.  The poll is bounded (~1 s; then the error word is raised and a zero state used), so the
-// grid always drains.
+// moment it reads as anything else.  Work items are handed out by an atomic ticket in the order the workgroups START, and the
+// segments of a stream hold consecutive tickets in their own order: whoever is waited for started earlier and is running or
+// done -- no dispatch order is assumed.  The poll is bounded (~1 s; then the error word is raised and the state is NaN, which
+// the segment's samples inherit: visible, never silent), so the grid always drains.
 __device__ __forceinline__ double chain_wait(const unsigned long long* word, int* err) {
   for (int it = 0; it < (1 << 22); ++it) {
     const unsigned long long v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -164,19 +185,23 @@ __device__ __forceinline__ double chain_wait(const unsigned long long* word, int
     __builtin_amdgcn_s_sleep(2);
   }
   atomicExch(err, 1);
-  return 0.0;
+  return __builtin_nan("");   // never silent: a segment whose predecessor did not deliver turns into NaN samples
 }
 __device__ __forceinline__ void chain_post(unsigned long long* word, double v) {
   __hip_atomic_store(word, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// z: in = zero-state final state of this thread's chunk, out = the chunk's true start state.  Thread 0 is the stream's relay: it
-// folds the waves' totals into the segment's aggregate Z (its final state from a zero start) BEFORE it waits for the previous
-// segment's state s (`prev`, NULL for the first segment), so that what the next segment waits for, M^kFT s + Z, leaves one
-// matrix-vector product after s arrives (`next`); then it leaves s in seg[] for everybody.
+// z: in = zero-state final state of this thread's chunk, out = the chunk's true start state.
+// Across segments (different workgroups) this is a DECOUPLED look-back: thread 0 folds the waves' totals into the segment's
+// aggregate Z (its final state from a zero start: needs nothing from other segments) and publishes it (`mine`); then the
+// workgroup reads the aggregates of ALL earlier segments of the stream (`first`, records `stride` words apart) -- in parallel,
+// one word per thread, polling the few that are not there yet -- and thread 0 folds them, s <- M^kFT s + Z_j for j = 0 .. nprev - 1,
+// into the state at this segment's start.  No segment waits for another one's RESULT, only for its aggregate, and all
+// aggregates of a stream are produced at about the same time: the serial hand-over chain of the first version (14 hops per
+// stream and filter) is one hop deep.
 template <int D>
-__device__ __forceinline__ void chain_scan(double (&z)[D], const double (*Mp)[16], double (*wtot)[4], double* seg, int tid,
-                                           const unsigned long long* prev, unsigned long long* next, int* err) {
+__device__ __forceinline__ void chain_scan(double (&z)[D], const double (*Mp)[16], double (*wtot)[4], double* seg, double* zin, int tid,
+                                           const unsigned long long* first, int stride, int nprev, unsigned long long* mine, int* err) {
   const int lane = tid & 63, wave = tid >> 6;
   double P[D];
 #pragma unroll
@@ -198,7 +223,7 @@ __device__ __forceinline__ void chain_scan(double (&z)[D], const double (*Mp)[16
     for (int i = 0; i < D; ++i) wtot[wave][i] = P[i];
   __syncthreads();
   if (tid == 0) {
-    double Z[D], s[D], t[D];
+    double Z[D], t[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) Z[i] = 0.0;
     for (int w = 0; w < kFW; ++w) {   // Z <- M^64 Z + W_w
@@ -207,10 +232,19 @@ __device__ __forceinline__ void chain_scan(double (&z)[D], const double (*Mp)[16
       for (int i = 0; i < D; ++i) Z[i] = t[i] + wtot[w][i];
     }
 #pragma unroll
-    for (int i = 0; i < D; ++i) s[i] = prev ? chain_wait(prev + i, err) : 0.0;
-    matvec<D>(Mp[kFPow - 1], s, t);
+    for (int i = 0; i < D; ++i) chain_post(mine + i, Z[i]);
+  }
+  for (int i = tid; i < nprev * D; i += kFT) zin[i] = chain_wait(first + (size_t)(i / D) * stride + (i % D), err);
+  __syncthreads();
+  if (tid == 0) {
+    double s[D], t[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) chain_post(next + i, t[i] + Z[i]);
+    for (int i = 0; i < D; ++i) s[i] = 0.0;
+    for (int j = 0; j < nprev; ++j) {
+      matvec<D>(Mp[kFPow - 1], s, t);
+#pragma unroll
+      for (int i = 0; i < D; ++i) s[i] = t[i] + zin[j * D + i];
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i) seg[i] = s[i];
   }
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
   const float gain = d.gain;
   const bool two = d.bw_sections > 1;
   ChainCarry* const mine = p.carry + (size_t)a * p.nseg + sg;
-  const ChainCarry* const prev = mine - 1;   // (only dereferenced for sg > 0)
+  const ChainCarry* const first = mine - sg;   // the stream's first segment (records 8 words apart)
   // mover mapping: piece i of a segment = 16-byte unit i * kFT + tid -> samples 4 (i kFT + tid) .. + 3 of the segment
   const int n0 = sg * kFS;
 #pragma unroll
@@ -297,8 +331,8 @@ __global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
     float* q = lds.tile + (u / kFL) * kFP + (u % kFL);
     q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
   }
-  if (has_t) chain_powers(lds.Mp[0], d.tilt_sos, 1, tid);   // (the loads above are in flight meanwhile)
-  if (has_b) chain_powers(lds.Mp[1], d.bw_sos, d.bw_sections, tid);
+  for (int i = tid; i < 2 * kFPow * 16; i += kFT)   // both filters' powers (zeros where a filter is off: never used)
+    (&lds.Mp[0][0][0])[i] = ((i < kFPow * 16) ? has_t : has_b) ? p.pow[(size_t)stream * 2 * (kFPow * 16) + i] : 0.0;
   __syncthreads();
   float* row = lds.tile + tid * kFP;
   const int nv = max(0, min(kFL, T - (n0 + tid * kFL)));   // samples of this thread's chunk inside the clip
@@ -327,7 +361,7 @@ __global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
   };
   if (has_t) {   // (1) + (2) of the tilt biquad
     walk([&](float v) { (void)biquad_step(kt, ts[0], ts[1], (double)(v * gain)); return v; }, false);
-    chain_scan<2>(ts, lds.Mp[0], lds.wtot, lds.seg, tid, sg > 0 ? prev->t : nullptr, mine->t, p.ticket + 1);
+    chain_scan<2>(ts, lds.Mp[0], lds.wtot, lds.seg, lds.zin, tid, first->t, 8, sg, mine->t, p.ticket + 1);
   }
   // (3) of the tilt biquad, gain, compressor; (1) of the low-pass
   walk([&](float v) {
@@ -342,10 +376,10 @@ __global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
   }, true);
   if (has_b) {
     if (two) {
-      chain_scan<4>(bs, lds.Mp[1], lds.wtot, lds.seg, tid, sg > 0 ? prev->b : nullptr, mine->b, p.ticket + 1);
+      chain_scan<4>(bs, lds.Mp[1], lds.wtot, lds.seg, lds.zin, tid, first->b, 8, sg, mine->b, p.ticket + 1);
     } else {
       double b2[2] = {bs[0], bs[1]};
-      chain_scan<2>(b2, lds.Mp[1], lds.wtot, lds.seg, tid, sg > 0 ? prev->b : nullptr, mine->b, p.ticket + 1);
+      chain_scan<2>(b2, lds.Mp[1], lds.wtot, lds.seg, lds.zin, tid, first->b, 8, sg, mine->b, p.ticket + 1);
       bs[0] = b2[0], bs[1] = b2[1];
     }
     walk([&](float v) {
@@ -479,9 +513,11 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
     }
   }
   FftPlan<kNfft>::run<1>(vv, lds.scr[wave], lds.tw, lane);
-  float2* dst = (KIND == 0 ? p.G + ((size_t)b * p.NP + item) * 1024 : p.X + ((size_t)b * p.NX + item) * 1024) + lane;
+  // spectrum layout [r / 2][lane][r & 1]: a lane's registers 2 k, 2 k + 1 are one 16-byte unit -- rev_mac_ifft_kernel reads them with
+  // ds_read_b128 (256 B/clk/CU; the ds_read2st64_b64 pairs hipcc makes of a [r][lane] layout move half of that)
+  float4* dst = reinterpret_cast<float4*>(KIND == 0 ? p.G + ((size_t)b * p.NP + item) * 1024 : p.X + ((size_t)b * p.NX + item) * 1024) + lane;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) dst[r * 64] = v[r];
+  for (int k = 0; k < 8; ++k) dst[k * 64] = make_float4(v[2 * k].x, v[2 * k].y, v[2 * k + 1].x, v[2 * k + 1].y);
 }
 
 // Spectral multiply-accumulate over the NP partitions + inverse FFT + redistribution.  A workgroup = 8 waves = 8 consecutive
@@ -491,8 +527,9 @@ __global__ __launch_bounds__(256) void rev_fft_kernel(const RevParams p) {
 // needs ONE new block, X[j0 - q], which replaces the block only step q - 1's last wave still used (a ring of 9 slots, so
 // that the write of step q never touches what step q - 1 reads: one barrier per step).  Global traffic per step: 16 KB per
 // workgroup instead of 128 KB.
-constexpr int kRevWaves = 8, kRevRing = kRevWaves + 1;
+constexpr int kRevWaves = 8, kRevRing = kRevWaves + 3;
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // acc + a * w (complex) as two packed FMAs, in the nesting the scalar form had: (acc + (-a.y w.y, a.y w.x)) + (a.x w.x, a.x w.y).
 // Inline asm: hipcc builds the swapped / negated operands of the packed form with v_mov + v_xor (2 moves per FMA).
 __device__ __forceinline__ v2f cmac(v2f acc, v2f a, v2f w) {
@@ -506,7 +543,7 @@ struct RevLds {
   union {
     struct {
       float2 X[kRevRing][1024];
-      float2 G[2][1024];
+      float2 G[4][1024];
     } r;
     float2 scr[kRevWaves][kNfft + kNfft / 8];   // the inverse FFT's scratch, after the last step
   } u;
@@ -554,24 +591,37 @@ __global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevP
   v2f acc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = v2f{0.f, 0.f};
+  // TWO steps per barrier: the pair (q, q + 1) needs the windows jb - q - 1 .. jb - q + 7 and two G blocks; what it writes (two new
+  // windows, two G blocks) goes to slots the previous pair -- which other waves may still be reading -- does not use: a ring of
+  // kRevWaves + 3 windows and four G buffers.
   for (int q0 = 0; q0 < p.NP; q0 += kRevAhead) {
 #pragma unroll
-    for (int u = 0; u < kRevAhead; ++u) {
-      const int q = q0 + u;
-      if (q < p.NP) {   // block-uniform
-        reinterpret_cast<float4*>(lds.u.r.G[q & 1])[tid] = gq[u];
-        if (q > 0) reinterpret_cast<float4*>(lds.u.r.X[slot(jb - q)])[tid] = xq[u];
-        __syncthreads();
-        issue(q + kRevAhead, gq[u], xq[u]);
-        const int i = j - q;
-        if (mine && i >= 0 && i < p.NX) {   // wave-uniform
-          const v2f* x = reinterpret_cast<const v2f*>(lds.u.r.X[slot(i)]) + lane;
-          const v2f* g = reinterpret_cast<const v2f*>(lds.u.r.G[q & 1]) + lane;
-          v2f a[16], w[16];   // all 32 reads in flight before the first multiply-add (one LDS round trip per step, not four)
+    for (int h = 0; h < kRevAhead / 2; ++h) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a[r] = x[r * 64], w[r] = g[r * 64];
+      for (int e = 0; e < 2; ++e) {
+        const int u = 2 * h + e, q = q0 + u;
+        if (q < p.NP) {   // block-uniform
+          reinterpret_cast<float4*>(lds.u.r.G[q & 3])[tid] = gq[u];
+          if (q > 0) reinterpret_cast<float4*>(lds.u.r.X[slot(jb - q)])[tid] = xq[u];
+        }
+      }
+      __syncthreads();
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = cmac(acc[r], a[r], w[r]);
+      for (int e = 0; e < 2; ++e) issue(q0 + 2 * h + e + kRevAhead, gq[2 * h + e], xq[2 * h + e]);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int q = q0 + 2 * h + e, i = j - q;
+        if (q < p.NP && mine && i >= 0 && i < p.NX) {   // wave-uniform
+          const f32x4* x = reinterpret_cast<const f32x4*>(lds.u.r.X[slot(i)]) + lane;
+          const f32x4* g = reinterpret_cast<const f32x4*>(lds.u.r.G[q & 3]) + lane;
+          f32x4 a[8], w[8];   // all 16 reads (16 bytes each) in flight before the first multiply-add: one LDS round trip per step
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[k] = x[k * 64], w[k] = g[k * 64];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            acc[2 * k] = cmac(acc[2 * k], v2f{a[k].x, a[k].y}, v2f{w[k].x, w[k].y});
+            acc[2 * k + 1] = cmac(acc[2 * k + 1], v2f{a[k].z, a[k].w}, v2f{w[k].z, w[k].w});
+          }
         }
       }
     }
@@ -657,7 +707,7 @@ __global__ __launch_bounds__(kRevWaves * 64) void rev_mac_ifft_kernel(const RevP
 }
 
 struct AugLayout {
-  size_t dec, act, lb, prop, epart, G, X, total;   // lb: ticket words + carry records (zeroed per launch)
+  size_t dec, act, pow, lb, prop, epart, G, X, total;   // lb: ticket words + carry records (zeroed per launch)
   size_t lb_bytes;
   int nseg, NP, NX, D, j0, nj;
 };
@@ -679,6 +729,7 @@ AugLayout aug_layout(int B, int T, int L) {
   a.dec = take((size_t)B * sizeof(mst_aug_clip));
   a.nseg = (T + kFS - 1) / kFS;
   a.act = take((size_t)(1 + B * 8) * sizeof(int));
+  a.pow = take((size_t)B * 8 * 2 * kFPow * 16 * sizeof(double));
   a.lb_bytes = 64 + (size_t)B * 8 * a.nseg * sizeof(ChainCarry);
   a.lb = take(a.lb_bytes);
   a.prop = take((size_t)B * 4 * sizeof(float));
@@ -738,12 +789,13 @@ int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* st
     }
   if (any_chain) {
     int* lb = reinterpret_cast<int*>(ws + L.lb);
-    ChainParams cp{stems_inout, ddec, T, clip_stride, B, L.nseg, reinterpret_cast<int*>(ws + L.act), lb,
+    ChainParams cp{stems_inout, ddec, T, clip_stride, B, L.nseg, reinterpret_cast<int*>(ws + L.act), reinterpret_cast<double*>(ws + L.pow), lb,
                    reinterpret_cast<ChainCarry*>(ws + L.lb + 64)};
     static_assert(sizeof(ChainCarry) == 64, "one carry record per 64 bytes");
     MST_HIP_CHECK(hipMemsetAsync(lb, 0, 64, st));
     MST_HIP_CHECK(hipMemsetAsync(ws + L.lb + 64, 0xFF, L.lb_bytes - 64, st));   // every carry word = kCarryEmpty
     hipLaunchKernelGGL(aug_active_kernel, dim3(1), dim3(64), 0, st, ddec, B, cp.act);
+    hipLaunchKernelGGL(aug_powers_kernel, dim3(B * 8), dim3(64), 0, st, ddec, cp.pow);
     static unsigned long long chain_attr = 0;   // per-device bit mask: the dynamic-LDS limit belongs to the device
     if (mst::first_use_on_device(chain_attr))
       MST_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(aug_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
