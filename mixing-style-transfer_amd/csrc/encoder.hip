@@ -200,7 +200,22 @@ struct ConvParams {
   // elements of the layout's 16-byte units' scalar type (floats: frames * cm_mels * 8)
   const void* in_lo;
   int cm_mels, cm_overlap;
+  // free-running kernels (conv1_resident_kernel, conv1_f16e_kernel): start-up delay of one of the two waves of every SIMD, in
+  // units of 1024 cycles (skew_waves below); 0 = none
+  int skew;
 };
+
+// Two waves that share a SIMD and start a tile together stay in lock step: they split the matrix pipe evenly through the
+// k-steps, finish them together and then both sit in staging / epilogue while the pipe idles.  Any offset between them
+// persists just the same (each wave's tile takes as long as the other's), so ONE delay at the start -- and after every
+// workgroup barrier, which lines the waves up again -- puts one wave's epilogue under the other's MFMAs for the whole run.
+// bit 8 of `skew` picks the waves: 0 = the upper half of the workgroup (wave w and w + NW / 2 share a SIMD when waves are dealt
+// round-robin), 1 = odd waves.
+__device__ __forceinline__ void skew_waves(int wave, int nw, int skew) {
+  const bool mine = (skew & 0x100) ? (wave & 1) : (2 * wave >= nw);
+  if (mine)
+    for (int i = 0; i < (skew & 0xff); ++i) __builtin_amdgcn_s_sleep(16);
+}
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // one lane-unit (NV accumulator slots) of the raw convolution output: fp32, or (y_scale != NULL) float16 times the band's scale
@@ -252,6 +267,16 @@ __device__ __forceinline__ void flush_stats(double (&st)[NT][2], mst::DetAcc* st
 struct Tile {
   int valid, clip, band, tr, tc;
 };
+
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 
 template <int LAYER, int SUB>
@@ -590,6 +615,14 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* wres = smem;                                // [2][WCH]
   float* pbuf = smem + 2 * WCH + wave * PATCH;
+  constexpr bool DYN = MODE == 0;                    // tiles by ticket (below); the training forward keeps the static deal: its
+                                                     // per-wave statistics sums are folded in a fixed order
+  constexpr int kTickets = 16;
+  __shared__ unsigned tickets[kTickets];
+#ifdef MST_TRACE
+  long long trc[5] = {0, 0, 0, 0, 0};   // cycles: k-steps, epilogue, stage + draw + setup, segment barrier + weights; tiles
+  const long long trc_start = clock64();
+#endif
 
   const int G = gridDim.x;
   const int wg = mst::xcd_remap(blockIdx.x, G);
@@ -692,51 +725,97 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 #pragma unroll
   for (int n = 0; n < NT; ++n) st[n][0] = st[n][1] = 0.0;
   int cur_band = -1;
-  Tile cur{}, nxt = decode(s_begin);
+  // DYN: the workgroup's run of sets [s_begin, s_end) cut at the (group, band) boundaries into segments; inside a segment the
+  // tiles go to whichever wave asks next (one LDS counter per segment, kTickets of them in rotation: a wave can be at most
+  // seven exhausted segments ahead of the slowest wave, each of the other seven holding at most one tile it has not computed)
+  const int spb = p.sets_per_band;
+  const int gb0 = s_begin / spb, nseg = s_end > s_begin ? (s_end - 1) / spb - gb0 + 1 : 0;
+  int dseg = 0, dlo = 0, dhi = 0, dgb = 0, nxt_seg = 0;
+  auto seg_range = [&](int k) __attribute__((always_inline)) {
+    dgb = gb0 + k;
+    const int cm = p.clip_major ? p.clip_major : p.B, grp = p.clip_major ? dgb / p.nsub : 0;
+    dlo = max(s_begin - dgb * spb, 0) * kConvWaves;
+    dhi = min((min(s_end, (dgb + 1) * spb) - dgb * spb) * kConvWaves, min(cm, p.B - grp * cm) * tpb);
+  };
+  // A ticket is ASKED FOR (one LDS atomic by lane 0) several k-steps before it is looked at, so its round trip is never waited for
+  unsigned tkv = 0;
+  auto ticket_issue = [&]() __attribute__((always_inline)) {
+    tkv = 0;
+    if (dseg < nseg && lane == 0)
+      tkv = __hip_atomic_fetch_add(&tickets[dseg % kTickets], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto ticket_take = [&]() __attribute__((always_inline)) {
+    Tile t{};
+    while (dseg < nseg) {
+      const int idx = dlo + (int)__builtin_amdgcn_readfirstlane(tkv);
+      if (idx < dhi) {
+        const int grp = p.clip_major ? dgb / p.nsub : 0;
+        const int cl = idx / tpb, ti = idx - cl * tpb;
+        t.valid = 1;
+        t.band = dgb - grp * p.nsub;
+        t.clip = grp * p.clip_major + cl;
+        t.tc = ti / p.tiles_r;
+        t.tr = ti - t.tc * p.tiles_r;
+        return t;
+      }
+      if (++dseg < nseg) seg_range(dseg);   // this segment is empty: on to the next one (a handful of times per launch)
+      ticket_issue();
+    }
+    return t;   // the run is empty
+  };
+  Tile cur{}, nxt{};
+  if constexpr (DYN) {
+    if (tid < kTickets) tickets[tid] = 0;
+    __syncthreads();
+    if (nseg > 0) seg_range(0);
+    ticket_issue();
+    nxt = ticket_take();
+    nxt_seg = dseg;
+  } else {
+    nxt = decode(s_begin);
+  }
   prefetch_setup(nxt);
 #pragma unroll
   for (int i = 0; i < NPF; ++i) prefetch_piece(i);
 
   // stage this wave's prefetched patch (wave-private: no barrier)
-  auto stage = [&]() __attribute__((always_inline)) {
+  // out-of-image elements of a fetched piece become zeros (the loads went to clamped addresses)
+  auto mask_piece = [&](int i) __attribute__((always_inline)) {
+    if constexpr (LAY == 0) {
+      pf[i] = (((rowmask >> i) & 1ull) && col_ok) ? pf[i] : 0.f;
+    } else {
+      const bool ok = (rowmask >> i) & 1ull;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pf[i][k] = ok ? pf[i][k] : 0.f;
+    }
+  };
+  // MASKED: the pieces are masked already (DYN: inside the k-steps) and this is LDS stores only
+  auto stage_ = [&](auto MASKED_) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(MASKED_)::value;
     if constexpr (LAY == 0) {
 #pragma unroll
-      for (int i = 0; i < NPF; ++i)
-        if (lane < PC) pbuf[i * PC + lane] = (((rowmask >> i) & 1ull) && col_ok) ? pf[i] : 0.f;
+      for (int i = 0; i < NPF; ++i) {
+        if (!MASKED) mask_piece(i);
+        if (lane < PC) pbuf[i * PC + lane] = pf[i];
+      }
     } else {
       float* pl = pbuf + (4 * lhalf) * CHS + lr * PC + lfq;
 #pragma unroll
       for (int i = 0; i < NPF; ++i) {
         if (4 * i + 3 < PC || 4 * i + lfq < PC) {
-          const bool ok = (rowmask >> i) & 1ull;
+          if (!MASKED) mask_piece(i);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) pl[k * CHS + 4 * i] = ok ? pf[i][k] : 0.f;
+          for (int k = 0; k < 4; ++k) pl[k * CHS + 4 * i] = pf[i][k];
         }
       }
     }
   };
-  // (staging the NEXT tile's patch before this tile's epilogue -- so that no tile opens behind the acknowledgement of the previous
-  // tile's stores in the in-order vmcnt counter -- measured 0.7 % SLOWER here: the 31 k MFMA cycles of a tile dwarf that wait)
-  for (int s = s_begin; s < s_end; ++s) {
-    cur = nxt;
-    if (cur.band != cur_band) {  // same `s` sequence in every wave: all eight reach this together
-      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
-      __syncthreads();
-      for (int c = 0; c < 2; ++c) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)cur.band * 2 + c) * WBP);
-        for (int k = tid; k < WCH / 4; k += kConvThreads) reinterpret_cast<f32x4*>(wres + c * WCH)[k] = src[k];
-      }
-      __syncthreads();
-      cur_band = cur.band;
-    }
-    stage();
-    nxt = decode(s + 1);
-    prefetch_setup(nxt);
-    if (!cur.valid) {
-#pragma unroll
-      for (int i = 0; i < NPF; ++i) prefetch_piece(i);
-      continue;
-    }
+  auto stage = [&]() __attribute__((always_inline)) { stage_(std::false_type{}); };
+  // one tile: k-steps (the next tile's patch is fetched meanwhile), then the epilogue
+  auto tile_body = [&]() __attribute__((always_inline)) {
+#ifdef MST_TRACE
+    const long long tr0 = clock64();
+#endif
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -767,6 +846,10 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         }
       }
     }
+#ifdef MST_TRACE
+    const long long tr1 = clock64();
+    trc[0] += tr1 - tr0, trc[4] += 1;
+#endif
     if constexpr (MODE == 1) {
       // training forward: raw output + bias in accumulator order, batch-statistics sums over the valid columns
       const int j = lane & 15, g = lane >> 4;
@@ -826,6 +909,211 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         }
       }
     }
+#ifdef MST_TRACE
+    trc[1] += clock64() - tr1;
+#endif
+  };
+  // ---- DYN (eval forward): everything of a tile that is not a matrix instruction or the staging of its patch rides INSIDE the
+  // k-steps, in the issue slots between the MFMAs: the ticket for the next tile, its decode and prefetch set-up, and the
+  // EPILOGUE OF THE PREVIOUS TILE (its accumulators are copied aside when its k-steps end).  A wave outside its k-steps shares
+  // the SIMD with one that is inside them and gets an issue slot every ~30-50 cycles: traced (MST_TRACE build) at 11 k cycles per
+  // epilogue and 13 k per staging + bookkeeping, against 31 k of MFMAs per tile -- the two waves of a SIMD were both outside their
+  // k-steps ~9 % of the time and the matrix pipe idled.  Inside the k-steps the same instructions cost nothing: they issue in the
+  // shadow of the wave's own 32-cycle MFMAs.
+  f32x4 sav[MT][NT];
+  float2 sav_ac[NT];
+  Tile prev{};
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) sav[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < NT; ++n) sav_ac[n] = float2{0.f, 0.f};
+  // (compile-time n, wv: as run-time lambda arguments they turned `sav` into a scratch array)
+  auto epi_part = [&](auto N_, auto WV_) __attribute__((always_inline)) {   // the pooled output(s) of window column wv, channel tile n, of `prev`
+    constexpr int n = decltype(N_)::value, wv = decltype(WV_)::value;
+    const int j = lane & 15, g = lane >> 4;
+    const int ch = n * 16 + j;
+    float* orow = p.out + ((size_t)prev.clip * p.nsub + prev.band) * C::COUT * p.out_rows * p.out_cols + (size_t)prev.tr * p.out_cols;
+    const float2 ac = sav_ac[n];
+    const int pc = 4 * C::WPG * prev.tc + C::WPG * g + wv;
+    if (SUB == 2 && p.pool_h == 1) {   // two 1 x 5 windows: positions 0..4 are tile row 0, 5..9 tile row 1
+#pragma unroll
+      for (int hr = 0; hr < 2; ++hr) {
+        float m = 0.f;
+#pragma unroll
+        for (int pos = 0; pos < 5; ++pos) {
+          const int e = wv * C::WIN + 5 * hr + pos;
+          m = fmaxf(m, fmaf(sav[e >> 2][n][e & 3], ac.x, ac.y));
+        }
+        if (prev.valid && pc < p.out_cols && 2 * prev.tr + hr < p.out_rows)
+          orow[(size_t)ch * p.out_rows * p.out_cols + (size_t)(prev.tr + hr) * p.out_cols + pc] = m;   // orow is at row tr: + tr + hr
+      }
+    } else {
+      float m = 0.f;
+#pragma unroll
+      for (int pos = 0; pos < C::WIN; ++pos) {
+        const int e = wv * C::WIN + pos;
+        m = fmaxf(m, fmaf(sav[e >> 2][n][e & 3], ac.x, ac.y));
+      }
+      if (prev.valid && pc < p.out_cols) orow[(size_t)ch * p.out_rows * p.out_cols + pc] = m;
+    }
+  };
+  auto tile_dyn = [&]() __attribute__((always_inline)) {
+#ifdef MST_TRACE
+    const long long tr0 = clock64();
+#endif
+    float2 e_ac[NT];   // requested now, used by the deferred epilogue
+    {
+      const float2* aff = p.aff + ((size_t)cur.clip * p.nsub + cur.band) * C::COUT;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) e_ac[n] = aff[n * 16 + (lane & 15)];
+    }
+    {
+      constexpr int kEpi0 = 12;   // first k-step that carries a part of the previous tile's epilogue (one part every second step)
+      float a[2][MT], b[2][NT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) a[0][t] = pbuf[abase[t]];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[0][n] = wres[n * 64 + lane];
+      // (static_for: with the ticket loop inside, `#pragma unroll` no longer unrolled the 98 steps and every compile-time index
+      // below became a run-time one)
+      static_for<98>([&](auto KS) __attribute__((always_inline)) {
+        constexpr int ks = decltype(KS)::value;
+        constexpr int cu = ks & 1, nx = cu ^ 1;
+        constexpr int tap = (ks + 1) >> 1, ch = (ks + 1) & 1;
+        constexpr int off = ch * 4 * CHS + (tap / 7) * PC + (tap % 7);
+#pragma unroll
+        for (int i = 0; i < MT * NT; ++i) {
+          const int t = i / NT, n = i % NT;
+          // (step 0 starts from a literal zero: no zeroing pass over the accumulators)
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[t][n], 0, 0, 0);
+          if (ks + 1 < 98) {
+            if (i < NT) b[nx][i] = wres[ch * WCH + (tap * NT + i) * 64 + lane];
+            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
+          }
+          if (i == MT + NT) {
+            // the next tile's patch: fetched in the first half of the k-steps (its set-up is in step 6), masked in the second
+            // half -- the loads have landed by then -- so that staging it is LDS stores alone
+            if constexpr (LAY == 0) {
+              if constexpr (ks >= 8 && ks < 8 + NPF / 2) prefetch_piece(2 * (ks - 8)), prefetch_piece(2 * (ks - 8) + 1);
+              if constexpr (ks >= 60 && ks < 60 + NPF / 2) mask_piece(2 * (ks - 60)), mask_piece(2 * (ks - 60) + 1);
+            } else {
+              if constexpr (ks >= 8 && ks % 4 == 0 && ks / 4 - 2 < NPF) prefetch_piece(ks / 4 - 2);
+              if constexpr (ks >= 60 && ks % 3 == 0 && ks / 3 - 20 < NPF) mask_piece(ks / 3 - 20);
+            }
+          }
+          if (i == MT + NT + 1) {
+            if constexpr (ks == 0) ticket_issue();
+            if constexpr (ks == 6) {
+              nxt = ticket_take();
+              nxt_seg = dseg;
+              prefetch_setup(nxt);
+            }
+            if constexpr (ks >= kEpi0 && ks < kEpi0 + 2 * NT * C::WPG && (ks - kEpi0) % 2 == 0)
+              epi_part(std::integral_constant<int, (ks - kEpi0) / 2 / C::WPG>{}, std::integral_constant<int, (ks - kEpi0) / 2 % C::WPG>{});
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    }
+    // hand the tile to the deferred epilogue.  The copy is made BY THE MATRIX PIPE (D = 0 x B + C, exact: the weights are finite;
+    // 10 MFMAs = 1 % of the tile's): as 40 v_mov after the last k-step it would be VALU work of a wave outside its k-steps
+    {
+      const float bz = wres[lane];
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) sav[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(0.f, bz, acc[t][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) sav_ac[n] = e_ac[n];
+    prev = cur;
+#ifdef MST_TRACE
+    trc[0] += clock64() - tr0, trc[4] += 1;
+#endif
+  };
+  auto load_band = [&](int band) __attribute__((always_inline)) {
+    for (int c = 0; c < 2; ++c) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(p.wfrag + ((size_t)band * 2 + c) * WBP);
+      for (int k = tid; k < WCH / 4; k += kConvThreads) reinterpret_cast<f32x4*>(wres + c * WCH)[k] = src[k];
+    }
+  };
+  if constexpr (DYN) {
+    bool first_tile = true;
+    // Tiles by ticket.  The SIMD's issue arbiter serves its OLDEST wave first: of the two waves that share a SIMD the older one
+    // takes every matrix-pipe slot it can use and the younger one advances only while the older sits in staging / epilogue /
+    // tile bookkeeping (~6 k of a tile's ~38 k cycles).  With tiles dealt statically (wave w takes tile 8 s + w) the older waves
+    // finished their halves with the pipe full and the younger ones then ran most of theirs ALONE, every epilogue in the open:
+    // SQ_VALU_MFMA_BUSY_CYCLES 90 % of the SIMD cycles (profiles/r04_conv_sq_counters.txt), no change from any start-up skew.
+    // Here a wave takes the next tile of the workgroup's run when it is ready for one, so both waves of a SIMD work until the
+    // run is empty.  Results do not depend on which wave computes a tile.
+    for (int k = 0; k < nseg; ++k) {
+#ifdef MST_TRACE
+      const long long tb0 = clock64();
+#endif
+      __syncthreads();                                   // every wave is done with the previous segment's weights
+      load_band((gb0 + k) % p.nsub);
+      if (tid == 0) tickets[(k + kTickets - 1) % kTickets] = 0;   // segment k - 1's counter: next used by segment k + kTickets - 1
+      __syncthreads();
+#ifdef MST_TRACE
+      trc[3] += clock64() - tb0;
+#endif
+      while (nxt.valid && nxt_seg == k) {
+#ifdef MST_TRACE
+        const long long ts0 = clock64();
+#endif
+        cur = nxt;
+#ifdef MST_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long ts1 = clock64();
+        trc[1] += ts1 - ts0;
+#endif
+        if (first_tile) stage_(std::false_type{});
+        else stage_(std::true_type{});   // LDS stores only: VALU instructions of a wave outside its k-steps wait for the partner's MFMA stream
+        first_tile = false;
+#ifdef MST_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        trc[2] += clock64() - ts1;
+#endif
+        tile_dyn();
+      }
+    }
+    {   // the last tile's epilogue
+      static_for<NT * C::WPG>([&](auto I) __attribute__((always_inline)) {
+        constexpr int q = decltype(I)::value;
+        epi_part(std::integral_constant<int, q / C::WPG>{}, std::integral_constant<int, q % C::WPG>{});
+      });
+    }
+#ifdef MST_TRACE
+    if (lane == 0 && p.yraw) {
+      float* o = p.yraw + (blockIdx.x * kConvWaves + wave) * 8;
+      for (int i = 0; i < 5; ++i) o[i] = (float)trc[i];
+      o[5] = (float)(clock64() - trc_start);
+    }
+#endif
+  } else {
+  // (staging the NEXT tile's patch before this tile's epilogue -- so that no tile opens behind the acknowledgement of the previous
+  // tile's stores in the in-order vmcnt counter -- measured 0.7 % SLOWER here: the 31 k MFMA cycles of a tile dwarf that wait)
+  for (int s = s_begin; s < s_end; ++s) {
+    cur = nxt;
+    if (cur.band != cur_band) {  // same `s` sequence in every wave: all eight reach this together
+      if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
+      __syncthreads();
+      load_band(cur.band);
+      __syncthreads();
+      cur_band = cur.band;
+    }
+    stage();
+    nxt = decode(s + 1);
+    prefetch_setup(nxt);
+    if (!cur.valid) {
+#pragma unroll
+      for (int i = 0; i < NPF; ++i) prefetch_piece(i);
+      continue;
+    }
+    tile_body();
+  }
   }
   if (MODE == 1 && cur_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, cur_band, lane);
 }
@@ -1366,6 +1654,7 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
       for (int k = tid; k < WV; k += NTHR) wres[k] = HL == 2 ? src[k] : src[((k >> 6) * 2) * 64 + (k & 63)];
       __syncthreads();
       cur_band = cur.band;
+      skew_waves(wave, NW, p.skew);
     }
     nxt = advance(cur, s + 1);
     prefetch_setup(nxt);
@@ -3278,6 +3567,10 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
     cp.tiles_r = e->H1;
     cp.tiles_c = e->sub == 2 ? (L.W1 + 7) / 8 : (L.W1 + 15) / 16;
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
+    {
+      const char* env = getenv("MST_CONV1_SKEW");
+      cp.skew = env ? atoi(env) : 0;
+    }
     const int g = std::min(grid, ns * cp.sets_per_band);
     hipError_t err;
     if (e->sub > 2) {   // first-pool heights >= 3: the generic kernel (reference layout, exact fp32)
@@ -3373,8 +3666,30 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return mst::fail(MST_EHIP, "conv1 attribute failed: %s", hipGetErrorString(err));
       }
+#ifdef MST_TRACE
+      static float* trace_buf = nullptr;
+      if (!trace_buf) (void)hipMalloc(&trace_buf, 256 * kConvWaves * 8 * sizeof(float));
+      cp.yraw = trace_buf;
+#endif
       if (lay == MST_LOGMEL_CM32) hipLaunchKernelGGL((conv1_resident_kernel<2, 0, 1>), dim3(g), dim3(kConvThreads), lds, st, cp);
       else hipLaunchKernelGGL((conv1_resident_kernel<2>), dim3(g), dim3(kConvThreads), lds, st, cp);
+#ifdef MST_TRACE
+      {
+        static int calls = 0;
+        if (++calls == 10) {
+          (void)hipDeviceSynchronize();
+          std::vector<float> h(256 * kConvWaves * 8);
+          (void)hipMemcpy(h.data(), trace_buf, h.size() * sizeof(float), hipMemcpyDeviceToHost);
+          for (int w = 0; w < kConvWaves; ++w) {   // average over the workgroups, per wave index
+            double a[6] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < g; ++b)
+              for (int i = 0; i < 6; ++i) a[i] += h[(b * kConvWaves + w) * 8 + i] / g;
+            fprintf(stderr, "trace wave %d: tiles %.1f  k-steps %.0f (%.0f per tile)  wait for the patch loads %.0f (%.0f)  stage %.0f (%.0f)  barriers %.0f  total %.0f\n",
+                    w, a[4], a[0], a[0] / a[4], a[1], a[1] / a[4], a[2], a[2] / a[4], a[3], a[5]);
+          }
+        }
+      }
+#endif
       err = hipGetLastError();
     } else {
       err = e->sub == 2 ? launch_conv<1, 2>(cp, g, st) : launch_conv<1, 1>(cp, g, st);
