@@ -200,22 +200,7 @@ struct ConvParams {
   // elements of the layout's 16-byte units' scalar type (floats: frames * cm_mels * 8)
   const void* in_lo;
   int cm_mels, cm_overlap;
-  // free-running kernels (conv1_resident_kernel, conv1_f16e_kernel): start-up delay of one of the two waves of every SIMD, in
-  // units of 1024 cycles (skew_waves below); 0 = none
-  int skew;
 };
-
-// Two waves that share a SIMD and start a tile together stay in lock step: they split the matrix pipe evenly through the
-// k-steps, finish them together and then both sit in staging / epilogue while the pipe idles.  Any offset between them
-// persists just the same (each wave's tile takes as long as the other's), so ONE delay at the start -- and after every
-// workgroup barrier, which lines the waves up again -- puts one wave's epilogue under the other's MFMAs for the whole run.
-// bit 8 of `skew` picks the waves: 0 = the upper half of the workgroup (wave w and w + NW / 2 share a SIMD when waves are dealt
-// round-robin), 1 = odd waves.
-__device__ __forceinline__ void skew_waves(int wave, int nw, int skew) {
-  const bool mine = (skew & 0x100) ? (wave & 1) : (2 * wave >= nw);
-  if (mine)
-    for (int i = 0; i < (skew & 0xff); ++i) __builtin_amdgcn_s_sleep(16);
-}
 
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 // one lane-unit (NV accumulator slots) of the raw convolution output: fp32, or (y_scale != NULL) float16 times the band's scale
@@ -914,12 +899,14 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
 #endif
   };
   // ---- DYN (eval forward): everything of a tile that is not a matrix instruction or the staging of its patch rides INSIDE the
-  // k-steps, in the issue slots between the MFMAs: the ticket for the next tile, its decode and prefetch set-up, and the
-  // EPILOGUE OF THE PREVIOUS TILE (its accumulators are copied aside when its k-steps end).  A wave outside its k-steps shares
-  // the SIMD with one that is inside them and gets an issue slot every ~30-50 cycles: traced (MST_TRACE build) at 11 k cycles per
-  // epilogue and 13 k per staging + bookkeeping, against 31 k of MFMAs per tile -- the two waves of a SIMD were both outside their
-  // k-steps ~9 % of the time and the matrix pipe idled.  Inside the k-steps the same instructions cost nothing: they issue in the
-  // shadow of the wave's own 32-cycle MFMAs.
+  // k-steps, in the issue slots between the MFMAs: the ticket for the next tile, its decode and prefetch set-up, the zero-fill of
+  // the fetched pieces, and the EPILOGUE OF THE PREVIOUS TILE (its accumulators are copied aside when its k-steps end).
+  // Why: a wave outside its k-steps shares the SIMD with one that is inside them, and VALU instructions of such a wave wait for
+  // gaps in the partner's MFMA stream (scripts/ubench_corun.hip: next to a saturating MFMA wave a v_cndmask / v_fma takes
+  // 1700-2300 cycles, a ds_write_b32 20).  Traced at the contract size (profiles/r04_conv1_wave_trace.txt): epilogue 11 k cycles,
+  // staging + bookkeeping 13 k per tile next to 31 k of MFMAs; with this structure 1.8-2.2 k (LDS stores alone).  Inside the
+  // k-steps the same instructions issue in the shadow of the wave's own 32-cycle MFMAs.  Effect on the kernel: MFMA pipe busy
+  // 90.2 -> 92.3 % of the SIMD cycles, 4.85 -> 4.83 ms (the copy costs 1 % more MFMAs).
   f32x4 sav[MT][NT];
   float2 sav_ac[NT];
   Tile prev{};
@@ -1041,13 +1028,11 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   };
   if constexpr (DYN) {
     bool first_tile = true;
-    // Tiles by ticket.  The SIMD's issue arbiter serves its OLDEST wave first: of the two waves that share a SIMD the older one
-    // takes every matrix-pipe slot it can use and the younger one advances only while the older sits in staging / epilogue /
-    // tile bookkeeping (~6 k of a tile's ~38 k cycles).  With tiles dealt statically (wave w takes tile 8 s + w) the older waves
-    // finished their halves with the pipe full and the younger ones then ran most of theirs ALONE, every epilogue in the open:
-    // SQ_VALU_MFMA_BUSY_CYCLES 90 % of the SIMD cycles (profiles/r04_conv_sq_counters.txt), no change from any start-up skew.
-    // Here a wave takes the next tile of the workgroup's run when it is ready for one, so both waves of a SIMD work until the
-    // run is empty.  Results do not depend on which wave computes a tile.
+    // Tiles by ticket.  The two waves that share a SIMD do not advance at the same rate (traced, MST_TRACE build: the waves
+    // dispatched first take ~57 % of a SIMD's MFMA slots), so with tiles dealt statically (wave w takes tile 8 s + w) the faster
+    // waves finished early and their partners ran the rest alone.  Here a wave takes the next tile of the workgroup's run when
+    // it is ready for one, and both waves of a SIMD work until the run is empty.  Results do not depend on which wave computes a
+    // tile.  (A start-up offset between the two waves of a SIMD -- s_sleep in one of them -- changed nothing.)
     for (int k = 0; k < nseg; ++k) {
 #ifdef MST_TRACE
       const long long tb0 = clock64();
@@ -1654,7 +1639,6 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
       for (int k = tid; k < WV; k += NTHR) wres[k] = HL == 2 ? src[k] : src[((k >> 6) * 2) * 64 + (k & 63)];
       __syncthreads();
       cur_band = cur.band;
-      skew_waves(wave, NW, p.skew);
     }
     nxt = advance(cur, s + 1);
     prefetch_setup(nxt);
@@ -3567,10 +3551,6 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
     cp.tiles_r = e->H1;
     cp.tiles_c = e->sub == 2 ? (L.W1 + 7) / 8 : (L.W1 + 15) / 16;
     cp.sets_per_band = (B * cp.tiles_r * cp.tiles_c + kConvWaves - 1) / kConvWaves;
-    {
-      const char* env = getenv("MST_CONV1_SKEW");
-      cp.skew = env ? atoi(env) : 0;
-    }
     const int g = std::min(grid, ns * cp.sets_per_band);
     hipError_t err;
     if (e->sub > 2) {   // first-pool heights >= 3: the generic kernel (reference layout, exact fp32)
