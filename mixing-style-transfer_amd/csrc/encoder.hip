@@ -398,8 +398,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) prefetch_piece(i);
   }
+#ifdef MST_TRACE
+  long long trc[5] = {0, 0, 0, 0, 0};   // cycles: staging, barrier wait, taps, -; chunks
+  const long long trc_start = clock64();
+#endif
   for (int q = 0; q < nq; ++q) {
     float* wb = wbuf + (q & 1) * WBP;
+#ifdef MST_TRACE
+    const long long tq0 = clock64();
+#endif
     // stage the prefetched chunk into LDS (unconditional stores; out-of-image elements become zeros)
 #pragma unroll
     for (int i = 0; i < NWF; ++i) reinterpret_cast<f32x4*>(wb)[tid + kConvThreads * i] = wreg[i];
@@ -415,7 +422,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
         if (row < 4 * PR && col < PC) pbuf[row * PC + col] = ((colmask >> i) & 1u) ? pf[i] : 0.f;
       }
     }
+#ifdef MST_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long long tq1 = clock64();
+#endif
     __syncthreads();
+#ifdef MST_TRACE
+    const long long tq2 = clock64();
+    trc[0] += tq1 - tq0, trc[1] += tq2 - tq1, trc[4] += 1;
+#endif
     cur = nxt;
     nxt = decode(q + 1);
     prefetch_setup(q + 1, nxt);   // past the end this re-reads valid memory and is never staged
@@ -455,6 +470,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
         }
       }
     }
+#ifdef MST_TRACE
+    trc[2] += clock64() - tq2;
+#endif
     if (MODE == 1 && chunk == NCH - 1 && cur.valid) {
       // training forward: raw output + bias in accumulator order, batch-statistics sums over the valid positions
       const int j = lane & 15, g = lane >> 4;
@@ -570,6 +588,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
       }
     }
   }
+#ifdef MST_TRACE
+  if (MODE == 0 && LAYER == 2 && lane == 0 && p.yraw) {
+    float* o = p.yraw + (blockIdx.x * kConvWaves + wave) * 8;
+    for (int i = 0; i < 5; ++i) o[i] = (float)trc[i];
+    o[5] = (float)(clock64() - trc_start);
+  }
+#endif
   if ((MODE == 1 || MODE == 3) && st_band >= 0) flush_stats<NT, C::COUT>(st, p.stats, st_band, lane);
 }
 
@@ -3710,7 +3735,29 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
       else hipLaunchKernelGGL((conv2_f16x3_kernel<3>), dim3(g), dim3(kConvThreads), lds, st, cp, ih, il, wf);
       err = hipGetLastError();
     } else {
+#ifdef MST_TRACE
+      static float* trace_buf2 = nullptr;
+      if (!trace_buf2) (void)hipMalloc(&trace_buf2, 256 * kConvWaves * 8 * sizeof(float));
+      cp.yraw = trace_buf2;
+#endif
       err = launch_conv<2, 2>(cp, g, st);
+#ifdef MST_TRACE
+      {
+        static int calls = 0;
+        if (++calls == 10) {
+          (void)hipDeviceSynchronize();
+          std::vector<float> h(256 * kConvWaves * 8);
+          (void)hipMemcpy(h.data(), trace_buf2, h.size() * sizeof(float), hipMemcpyDeviceToHost);
+          for (int w = 0; w < kConvWaves; ++w) {
+            double a[6] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < g; ++b)
+              for (int i = 0; i < 6; ++i) a[i] += h[(b * kConvWaves + w) * 8 + i] / g;
+            fprintf(stderr, "conv2 trace wave %d: chunks %.1f  staging %.0f (%.0f per chunk)  barrier wait %.0f (%.0f)  taps %.0f (%.0f)  total %.0f\n",
+                    w, a[4], a[0], a[0] / a[4], a[1], a[1] / a[4], a[2], a[2] / a[4], a[5]);
+          }
+        }
+      }
+#endif
     }
     if (err != hipSuccess) return mst::fail(MST_EHIP, "conv2 launch failed: %s", hipGetErrorString(err));
   }
