@@ -323,8 +323,8 @@ def main():
             if timed:
                 e0.record()
             if a.aug:   # negatives = degraded anchors (README triplet design): clips 2, 5, 8, ... of the batch
-                xa[2::3].copy_(x[2::3])   # the reference's `.clone()` (src/mixing_utils.py:386) ...
-                augm.augment_packed_(xa[2::3], decisions=pending.pop() if pending else None)   # ... augmented where it stands
+                # xa[neg] = augment(x[neg]): the reference's `.clone()` (src/mixing_utils.py:386) is the chain's own first read
+                augm.augment_packed_(xa[2::3], decisions=pending.pop() if pending else None, src=x[2::3])
                 feats, logmel = fe.features_and_logmel(stems_aug, lay, lay == mlib.LOGMEL_CM16)
                 last["stems"] = stems_aug
             elif stager is not None:

@@ -378,6 +378,14 @@ int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* st
                           const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* Out of place: stems_out[b] = augment(src[b]) -- the reference's `stems.clone()` (src/mixing_utils.py:386) folded into the
+ * first pass over the audio instead of a copy before it.  src: dev, B clips `src_stride` floats apart, never written; stems_out:
+ * dev, B clips `clip_stride` floats apart, every sample written (a stem without a decision is copied).  The address ranges of
+ * src and stems_out must be disjoint (MST_EINVAL otherwise); src == stems_out with equal strides is mst_aug_apply_strided.  */
+int mst_aug_apply_from(const mst_aug_clip* decisions, int B, int T, const float* src, long long src_stride,
+                       float* stems_out, long long clip_stride, const float* reverb_ir, int ir_len,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training forward / backward of the two small networks around the convolution trunk, fp32, deterministic
  * (fixed-order reductions, no atomics), Dropout masks never stored -- a keep decision is a pure function of

@@ -161,6 +161,8 @@ SYMBOLS = {
                                 C.c_size_t, C.c_void_p]),
     "mst_aug_apply_strided": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int,
                                         C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mst_aug_apply_from": (C.c_int, [C.POINTER(AugClip), C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                     C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mst_infonce_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "mst_infonce_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

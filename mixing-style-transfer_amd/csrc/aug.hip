@@ -32,7 +32,9 @@ struct ChainCarry {           // what segment k of a stream publishes: its AGGRE
 };
 constexpr unsigned long long kCarryEmpty = ~0ull;   // (all ones: a NaN pattern no arithmetic produces; hipMemset 0xFF)
 struct ChainParams {
-  float* stems;              // [B][8][T]
+  float* stems;              // [B][8][T]: written (and, in place, read)
+  const float* src;          // read from: == stems (in place), or the tensor the reference would have cloned (mst_aug_apply_from)
+  long long src_stride;      // floats between the clips of src
   const mst_aug_clip* dec;   // device copy [B]
   int T;
   long long clip_stride;     // floats between clips (8 * T when packed)
@@ -275,7 +277,8 @@ __device__ __forceinline__ void chain_scan(double (&z)[D], const double (*Mp)[16
 }
 
 // one wave: the streams that have a decision -> act[0] = their number, act[1 ..] = their indices (clip * 8 + channel)
-__global__ __launch_bounds__(64) void aug_active_kernel(const mst_aug_clip* dec, int B, int* act) {
+// all != 0 (out of place): every stream -- one without a decision is copied by the chain kernel
+__global__ __launch_bounds__(64) void aug_active_kernel(const mst_aug_clip* dec, int B, int* act, int all) {
   const int lane = threadIdx.x;
   int n = 0;
   for (int s0 = 0; s0 < B * 8; s0 += 64) {
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(64) void aug_active_kernel(const mst_aug_clip* dec,
     bool on = false;
     if (stream < B * 8) {
       const mst_aug_stem& d = dec[stream >> 3].stem[(stream & 7) >> 1];
-      on = d.gain != 1.0f || d.tilt != 0 || d.compress != 0 || d.bw_sections > 0;
+      on = all || d.gain != 1.0f || d.tilt != 0 || d.compress != 0 || d.bw_sections > 0;
     }
     const unsigned long long m = __ballot(on);
     if (on) act[1 + n + __popcll(m & ((1ull << lane) - 1ull))] = stream;
@@ -305,8 +308,9 @@ __global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
   const mst_aug_stem& d = p.dec[stream >> 3].stem[(stream & 7) >> 1];
   const bool has_t = d.tilt != 0, has_c = d.compress != 0, has_b = d.bw_sections > 0;
   float* x = p.stems + (size_t)(stream >> 3) * p.clip_stride + (size_t)(stream & 7) * p.T;
+  const float* xin = p.src + (size_t)(stream >> 3) * p.src_stride + (size_t)(stream & 7) * p.T;
   const int T = p.T;
-  const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;   // 16-byte accesses (else four 4-byte ones)
+  const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(xin)) & 15) == 0;   // 16-byte accesses (else four 4-byte ones)
   const Coef kt = coef_of(d.tilt_sos), kb0 = coef_of(d.bw_sos), kb1 = coef_of(d.bw_sos + 6);
   const Comp kc = comp_of(d);
   const float gain = d.gain;
@@ -321,12 +325,12 @@ __global__ __launch_bounds__(kFT) void aug_chain_kernel(const ChainParams p) {
     const long long n = (long long)n0 + u;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n + 3 < T) {
-      if (vec) v = *reinterpret_cast<const float4*>(x + n);
-      else v = make_float4(x[n], x[n + 1], x[n + 2], x[n + 3]);
+      if (vec) v = *reinterpret_cast<const float4*>(xin + n);
+      else v = make_float4(xin[n], xin[n + 1], xin[n + 2], xin[n + 3]);
     } else if (n < T) {
-      v.x = x[n];
-      if (n + 1 < T) v.y = x[n + 1];
-      if (n + 2 < T) v.z = x[n + 2];
+      v.x = xin[n];
+      if (n + 1 < T) v.y = xin[n + 1];
+      if (n + 2 < T) v.z = xin[n + 2];
     }
     float* q = lds.tile + (u / kFL) * kFP + (u % kFL);
     q[0] = v.x, q[1] = v.y, q[2] = v.z, q[3] = v.w;
@@ -756,8 +760,25 @@ int mst_aug_apply(const mst_aug_clip* decisions, int B, int T, float* stems_inou
 
 int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* stems_inout, long long clip_stride,
                           const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes, void* stream) {
-  MST_REQUIRE(decisions && stems_inout, "mst_aug_apply: NULL argument");
+  return mst_aug_apply_from(decisions, B, T, stems_inout, clip_stride, stems_inout, clip_stride, reverb_ir, ir_len, workspace,
+                            workspace_bytes, stream);
+}
+
+int mst_aug_apply_from(const mst_aug_clip* decisions, int B, int T, const float* src, long long src_stride, float* stems_inout,
+                       long long clip_stride, const float* reverb_ir, int ir_len, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  MST_REQUIRE(decisions && stems_inout && src, "mst_aug_apply: NULL argument");
   MST_REQUIRE(clip_stride >= (long long)8 * T, "mst_aug_apply_strided: clip_stride %lld < 8 * T", clip_stride);
+  MST_REQUIRE(src_stride >= (long long)8 * T, "mst_aug_apply_from: src_stride %lld < 8 * T", src_stride);
+  const bool in_place = src == stems_inout;
+  MST_REQUIRE(!in_place || src_stride == clip_stride, "mst_aug_apply_from: src == dst with different strides");
+  if (!in_place && B > 0 && T > 0) {   // the two tensors must not overlap: a stream's segments are read and written by different workgroups
+    const char* a0 = reinterpret_cast<const char*>(src);
+    const char* a1 = a0 + ((size_t)(B - 1) * src_stride + (size_t)8 * T) * sizeof(float);
+    const char* b0 = reinterpret_cast<const char*>(stems_inout);
+    const char* b1 = b0 + ((size_t)(B - 1) * clip_stride + (size_t)8 * T) * sizeof(float);
+    MST_REQUIRE(a1 <= b0 || b1 <= a0, "mst_aug_apply_from: src and dst overlap");
+  }
   MST_REQUIRE(B > 0 && T > 0 && ir_len >= 0, "mst_aug_apply: bad sizes B=%d T=%d ir_len=%d", B, T, ir_len);
   bool any_rev = false;
   for (int b = 0; b < B; ++b) {
@@ -787,14 +808,15 @@ int mst_aug_apply_strided(const mst_aug_clip* decisions, int B, int T, float* st
       const mst_aug_stem& d = decisions[b].stem[s];
       any_chain = any_chain || d.gain != 1.0f || d.tilt != 0 || d.compress != 0 || d.bw_sections > 0;
     }
+  any_chain = any_chain || !in_place;   // out of place the chain is also the copy
   if (any_chain) {
     int* lb = reinterpret_cast<int*>(ws + L.lb);
-    ChainParams cp{stems_inout, ddec, T, clip_stride, B, L.nseg, reinterpret_cast<int*>(ws + L.act), reinterpret_cast<double*>(ws + L.pow), lb,
+    ChainParams cp{stems_inout, src, src_stride, ddec, T, clip_stride, B, L.nseg, reinterpret_cast<int*>(ws + L.act), reinterpret_cast<double*>(ws + L.pow), lb,
                    reinterpret_cast<ChainCarry*>(ws + L.lb + 64)};
     static_assert(sizeof(ChainCarry) == 64, "one carry record per 64 bytes");
     MST_HIP_CHECK(hipMemsetAsync(lb, 0, 64, st));
     MST_HIP_CHECK(hipMemsetAsync(ws + L.lb + 64, 0xFF, L.lb_bytes - 64, st));   // every carry word = kCarryEmpty
-    hipLaunchKernelGGL(aug_active_kernel, dim3(1), dim3(64), 0, st, ddec, B, cp.act);
+    hipLaunchKernelGGL(aug_active_kernel, dim3(1), dim3(64), 0, st, ddec, B, cp.act, in_place ? 0 : 1);
     hipLaunchKernelGGL(aug_powers_kernel, dim3(B * 8), dim3(64), 0, st, ddec, cp.pow);
     static unsigned long long chain_attr = 0;   // per-device bit mask: the dynamic-LDS limit belongs to the device
     if (mst::first_use_on_device(chain_attr))

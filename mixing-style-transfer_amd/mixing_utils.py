@@ -384,8 +384,9 @@ class AudioAugmenter:
         return ir, trace
 
     # -- device side ---------------------------------------------------------------------------
-    def _apply(self, x8, clips, irs):
-        """x8 (B, 8, T) fp32 CUDA, modified in place; every clip's (8, T) block contiguous, clips any stride >= 8 T apart."""
+    def _apply(self, x8, clips, irs, src=None):
+        """x8 (B, 8, T) fp32 CUDA, modified in place; every clip's (8, T) block contiguous, clips any stride >= 8 T apart.
+        src: read the audio from this (B, 8, T) tensor instead (never written; x8 is then output only, `mst_aug_apply_from`)."""
         if not x8.is_cuda:
             raise _lib.MstError("libmst kernels need CUDA (HIP) tensors; got a CPU tensor and there is no CPU fallback")
         B, _, T = x8.shape
@@ -411,9 +412,16 @@ class AudioAugmenter:
         if self._ws is None or self._ws.numel() < need or self._ws.device != x8.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x8.device)
         with torch.cuda.device(x8.device):
-            _lib.check(L.mst_aug_apply_strided(clips, B, T, _lib.dptr(x8), x8.stride(0) if B > 1 else 8 * T, _lib.dptr(ir_dev),
-                                               ir_len, _lib.dptr(self._ws), need, _lib.stream_ptr(x8.device)),
-                       "mst_aug_apply_strided")
+            if src is None:
+                _lib.check(L.mst_aug_apply_strided(clips, B, T, _lib.dptr(x8), x8.stride(0) if B > 1 else 8 * T, _lib.dptr(ir_dev),
+                                                   ir_len, _lib.dptr(self._ws), need, _lib.stream_ptr(x8.device)),
+                           "mst_aug_apply_strided")
+            else:
+                assert src.is_cuda and src.device == x8.device and src.dtype == torch.float32 and tuple(src.shape) == (B, 8, T)
+                assert src.stride(2) == 1 and src.stride(1) == T and (B == 1 or src.stride(0) >= 8 * T)
+                _lib.check(L.mst_aug_apply_from(clips, B, T, _lib.dptr(src), src.stride(0) if B > 1 else 8 * T, _lib.dptr(x8),
+                                                x8.stride(0) if B > 1 else 8 * T, _lib.dptr(ir_dev), ir_len, _lib.dptr(self._ws),
+                                                need, _lib.stream_ptr(x8.device)), "mst_aug_apply_from")
         return x8
 
     def draw_decisions(self, n_clips):
@@ -435,14 +443,16 @@ class AudioAugmenter:
         out = {s: x8[:, 2 * i:2 * i + 2] for i, s in enumerate(STEMS)}
         return out if batched else {s: v[0] for s, v in out.items()}
 
-    def augment_packed_(self, x8, decisions=None):
+    def augment_packed_(self, x8, decisions=None, src=None):
         """IN PLACE on a packed (B, 8, T) CUDA fp32 tensor (channels vL, vR, bL, bR, dL, dR, oL, oR) whose clips may be
         strided -- e.g. `batch[2::3]`, the negatives of a triplet batch, augmented where they stand (the caller has already
-        made the copy the reference's `.clone()` stands for).  Same decisions / RNG order as `augment_stems`."""
+        made the copy the reference's `.clone()` stands for).  Same decisions / RNG order as `augment_stems`.
+        src: a (B, 8, T) tensor in other memory to read the audio from -- x8 = augment(src), src untouched: the reference's
+        `.clone()` (src/mixing_utils.py:386) rides in the chain's first pass instead of being a copy before it."""
         clips, irs, traces = decisions if decisions is not None else self.draw_decisions(x8.shape[0])
         assert len(irs) == x8.shape[0]
         self.last_trace = traces
-        return self._apply(x8, clips, irs)
+        return self._apply(x8, clips, irs, src)
 
     def _single(self, audio, fill):
         """Run one effect on a (2, T) tensor: it rides as the first stem of an otherwise silent clip."""

@@ -198,6 +198,39 @@ def test_packed_strided_in_place_variant_equals_augment_stems():
         assert not torch.equal(y[0], x[0])
 
 
+def test_out_of_place_variant_equals_clone_then_in_place():
+    """`augment_packed_(dst, src=...)` (`mst_aug_apply_from`): dst = augment(src) bit-equal to the reference's order -- clone, then
+    augment the clone (src/mixing_utils.py:386) -- with src untouched; a clip WITHOUT any decision is copied; overlapping tensors
+    are refused."""
+    from mst_amd import _lib
+    from mst_amd.mixing_utils import AudioAugmenter
+    for T in (44100, 33075):
+        x = torch.stack([cases.synth_clip(c, T) for c in range(7)], 0).cuda()
+        keep = x.clone()
+        aug = AudioAugmenter()
+        torch.manual_seed(21)
+        dec = aug.draw_decisions(3)
+        ref = x.clone()
+        aug.augment_packed_(ref[0::3], decisions=dec)
+        y = torch.full_like(x, float("nan"))
+        aug.augment_packed_(y[0::3], decisions=dec, src=x[0::3])
+        torch.cuda.synchronize()
+        assert torch.equal(x, keep), "src was written"
+        assert torch.equal(y[0::3], ref[0::3])
+        assert bool(torch.isnan(y[1]).all()), "clips between the strided ones were touched"
+        # no decision at all: a plain copy
+        clips = (_lib.AugClip * 2)()
+        for b in range(2):
+            for i in range(4):
+                clips[b].stem[i].gain = 1.0
+        z = torch.full((2, 8, T), float("nan"), device="cuda")
+        aug.augment_packed_(z, decisions=(clips, [None, None], [{}, {}]), src=x[1:3])
+        torch.cuda.synchronize()
+        assert torch.equal(z, x[1:3])
+    with pytest.raises(_lib.MstError, match="overlap"):
+        aug.augment_packed_(x[1:3], decisions=(clips, [None, None], [{}, {}]), src=x[0:2])
+
+
 def test_infonce_deferred_guard_raises_one_call_later_and_corrupts_nothing():
     """`InfoNCELoss(check="deferred")`: the reference's "No positive pairs found in batch!" RuntimeError (src/loss.py) without a
     device -> host read per call -- a batch without positives gives a ZERO loss with zero gradients, and the error is raised by the
