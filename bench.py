@@ -26,6 +26,8 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 measured copy)
 MFMA_F32_PEAK_TF = 157.3     # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32 / 16x16x4_f32)
 MFMA_F16_PEAK_TF = 2500.0    # dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense; the 5 PF headline is 2:1 sparsity)
+MFMA_F16_SUSTAINED_TF = 2000.0   # what a pure f16 MFMA stream holds on operands that toggle (scripts/ubench_mfma.hip mode 4,
+                                 # profiles/r04_ubench_mfma_corun.txt: the chip clocks down to ~1.9 GHz); reported beside the peak, never instead of it
 
 
 def parse():
@@ -515,6 +517,7 @@ def main():
                        "roofline": {"bound": "mfma", "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "mfma_terms": terms,
                                     "conv1_achieved_executed": round(terms * fl1 / (k_ms[1] * 1e-3) / 1e12, 1),
                                     "conv1_frac": round(terms * fl1 / (k_ms[1] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
+                                    "sustained_on_random_operands": MFMA_F16_SUSTAINED_TF,
                                     "conv2_achieved_executed": round(terms * fl2 / (k_ms[2] * 1e-3) / 1e12, 1),
                                     "conv2_frac": round(terms * fl2 / (k_ms[2] * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4)},
                        "embedding_error_vs_fp32_kernels": {

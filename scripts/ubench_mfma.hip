@@ -4,6 +4,7 @@
 // MODE 1: the same with 7 ds_read_b32 per 10 MFMAs interleaved one per MFMA (conv1_resident_kernel's k-step)
 // MODE 2: f16 16x16x32, 10 accumulators x 3 dependent terms, nothing else
 // MODE 3: the same with 14 ds_read_b128 in front of every 30 MFMAs (conv1_f16e_kernel<3>'s k-step)
+// MODE 4 / 5: modes 2 / 0 on PSEUDO-RANDOM operands (every lane, register and half different): the power of real data
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -12,16 +13,28 @@ template <int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void k(float* out, int iters) {
   extern __shared__ float smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < NW * 2304; i += NW * 64) smem[i] = (float)(i & 7) * 0.125f;
+  for (int i = threadIdx.x; i < NW * 2304; i += NW * 64) {
+    if (MODE >= 4) {
+      unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+      h ^= h >> 15, h *= 2246822519u, h ^= h >> 13;
+      if (MODE == 4) {   // two float16 in [-1, 1)
+        const _Float16 lo = (_Float16)((float)(h & 0xffff) / 32768.f - 1.f), hi = (_Float16)((float)(h >> 16) / 32768.f - 1.f);
+        unsigned short a, b;
+        __builtin_memcpy(&a, &lo, 2), __builtin_memcpy(&b, &hi, 2);
+        const unsigned w = a | ((unsigned)b << 16);
+        __builtin_memcpy(&smem[i], &w, 4);
+      } else smem[i] = (float)(h >> 8) / 8388608.f - 1.f;
+    } else smem[i] = (float)(i & 7) * 0.125f;
+  }
   __syncthreads();
   f32x4 acc[5][2];
   for (int t = 0; t < 5; ++t)
     for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (MODE <= 1) {
+  if (MODE <= 1 || MODE == 5) {
     const float* pb = smem + wave * 2304 + lane;
     float a[2][5], b[2][2];
-    for (int t = 0; t < 5; ++t) a[0][t] = a[1][t] = pb[64 * t];
-    for (int n = 0; n < 2; ++n) b[0][n] = b[1][n] = pb[64 * (5 + n)];
+    for (int t = 0; t < 5; ++t) a[0][t] = pb[64 * t], a[1][t] = pb[64 * (t + 8)];
+    for (int n = 0; n < 2; ++n) b[0][n] = pb[64 * (5 + n)], b[1][n] = pb[64 * (13 + n)];
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int ks = 0; ks < 14; ++ks) {
@@ -40,8 +53,8 @@ __global__ __launch_bounds__(NW * 64) void k(float* out, int iters) {
   } else {
     const h16x8* pb = reinterpret_cast<const h16x8*>(smem + wave * 2304) + lane;
     h16x8 ah[2][5], al[2][5], bh[2][2], bl[2][2];
-    for (int t = 0; t < 5; ++t) ah[0][t] = ah[1][t] = al[0][t] = al[1][t] = pb[t];
-    for (int n = 0; n < 2; ++n) bh[0][n] = bh[1][n] = bl[0][n] = bl[1][n] = pb[5 + n];
+    for (int t = 0; t < 5; ++t) ah[0][t] = pb[64 * t], ah[1][t] = pb[64 * t + 320], al[0][t] = pb[64 * t + 1], al[1][t] = pb[64 * t + 321];
+    for (int n = 0; n < 2; ++n) bh[0][n] = pb[64 * n + 2], bh[1][n] = pb[64 * n + 322], bl[0][n] = pb[64 * n + 3], bl[1][n] = pb[64 * n + 323];
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
       for (int ks = 0; ks < 14; ++ks) {
@@ -80,9 +93,9 @@ void run(float* d, int iters) {
   hipEventSynchronize(b);
   float ms;
   hipEventElapsedTime(&ms, a, b);
-  const double n_mfma = (double)iters * 14 * (MODE <= 1 ? 10 : 30) * NW * 256;
-  const double flops = n_mfma * (MODE <= 1 ? 16 * 16 * 4 * 2 : 16 * 16 * 32 * 2);
-  const double cyc_per = ms * 1e-3 * 2.4e9 / ((double)iters * 14 * (MODE <= 1 ? 10 : 30) * (NW / 4));
+  const double n_mfma = (double)iters * 14 * ((MODE <= 1 || MODE == 5) ? 10 : 30) * NW * 256;
+  const double flops = n_mfma * ((MODE <= 1 || MODE == 5) ? 16 * 16 * 4 * 2 : 16 * 16 * 32 * 2);
+  const double cyc_per = ms * 1e-3 * 2.4e9 / ((double)iters * 14 * ((MODE <= 1 || MODE == 5) ? 10 : 30) * (NW / 4));
   printf("mode %d  %2d waves/CU  %.3f ms  %.1f TFLOP/s  %.2f cycles (at 2.4 GHz) per MFMA per SIMD\n", MODE, NW, ms, flops / ms * 1e-9, cyc_per);
 }
 int main() {
@@ -90,5 +103,6 @@ int main() {
   hipMalloc(&d, 256 * 1024 * 4);
   run<0, 4>(d, 2000), run<0, 8>(d, 1000), run<1, 4>(d, 2000), run<1, 8>(d, 1000), run<1, 12>(d, 700);
   run<2, 4>(d, 2000), run<2, 8>(d, 1000), run<3, 4>(d, 2000), run<3, 8>(d, 1000), run<3, 12>(d, 700);
+  run<4, 8>(d, 1000), run<4, 8>(d, 20000), run<5, 8>(d, 1000), run<5, 8>(d, 5000);
   return 0;
 }
