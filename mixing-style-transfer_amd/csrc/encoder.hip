@@ -1691,31 +1691,35 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-      // fragments of k-step st + 1 are read from LDS while the MFMAs of step st run (double-buffered registers); every A address
-      // is a lane base (even / odd steps) plus a compile-time offset: tap column st >> 1, M-tile column pair 2 t
-      constexpr bool DB = true;
-      h16x8 ah[DB ? 2 : 1][MT], al[DB ? 2 : 1][MT], bh[DB ? 2 : 1][NT], bl[DB ? 2 : 1][NT];
-      auto read_step = [&](int st, int buf) __attribute__((always_inline)) {
-        const h16x8* pa = phi + ((st & 1) ? base1 : base0) + (st >> 1);
-        const h16x8* pl = plo + ((st & 1) ? base1 : base0) + (st >> 1);
+      // The 14 k-steps run half by half (tap rows 0..3, then 4..6), tap column by tap column, and A FRAGMENTS ARE SHARED BETWEEN
+      // TAP COLUMNS: M-tile t at tap column c is the patch units of columns 10 g + 2 t + dc + c -- the very registers M-tile t + 1
+      // held at column c - 2.  So per half and column parity there are 8 (7) distinct fragments, "virtual M-tiles" j = t + (c >> 1),
+      // each read from LDS ONCE: 15 reads per half instead of 35; with the weights, 116 ds_read_b128 per tile instead of 196 (the
+      // LDS data path was busy 55-70 % of the kernel).  Fragments of the NEXT step are requested while the MFMAs of this one run;
+      // every address is a lane base (half) plus a compile-time offset.
+      h16x8 Rh[2][2][8], Rl[2][2][TERMS == 3 ? 8 : 1], bh[2][NT], bl[2][NT];
+      auto read_for = [&](int q) __attribute__((always_inline)) {   // what sequence step q needs and no register holds yet
+        const int half = q / 7, c = q % 7, par = c & 1, st = 2 * c + half, buf = q & 1;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           bh[buf][n] = wres[((st * NT + n) * HL + 0) * 64 + lane];
           if (TERMS == 3) bl[buf][n] = wres[((st * NT + n) * HL + 1) * 64 + lane];
         }
+        const h16x8* pa = phi + (half ? base1 : base0) + par;
+        const h16x8* pl = plo + (half ? base1 : base0) + par;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-          ah[buf][t] = pa[2 * t];
-          if (TERMS == 3) al[buf][t] = pl[2 * t];
-        }
+        for (int j = 0; j < 8; ++j)
+          if (c < 2 ? j < MT : j == MT - 1 + (c >> 1)) {
+            Rh[half][par][j] = pa[2 * j];
+            if (TERMS == 3) Rl[half][par][j] = pl[2 * j];
+          }
       };
-      if (DB) read_step(0, 0);
-#pragma unroll
-      for (int st = 0; st < kF16StepsE; ++st) {
-        const int cu = DB ? (st & 1) : 0, nx = cu ^ 1;
-        if (!DB) read_step(st, 0);
-        else if (st + 1 < kF16StepsE) read_step(st + 1, nx);
-        prefetch_piece(st);                                       // 6 (+ 6) 16-byte loads of the next tile, in the first six steps
+      read_for(0);
+      static_for<kF16StepsE>([&](auto Q_) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q_)::value;
+        constexpr int half = q / 7, c = q % 7, par = c & 1, sh = c >> 1, cu = q & 1;
+        if constexpr (q + 1 < kF16StepsE) read_for(q + 1);
+        prefetch_piece(q);                                        // 6 (+ 6) 16-byte loads of the next tile, in the first six steps
         // pin the reads IN FRONT of this step's MFMAs: left to itself the scheduler sinks them into the middle of the step and the
         // next step opens with an exposed LDS round trip (counted lgkmcnt waits two MFMAs after the reads)
         __builtin_amdgcn_sched_barrier(0);
@@ -1724,13 +1728,13 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             if (TERMS == 3) {
-              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);  // small terms first
-              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bl[cu][n], acc[t][n], 0, 0, 0);
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Rl[half][par][TERMS == 3 ? t + sh : 0], bh[cu][n], acc[t][n], 0, 0, 0);  // small terms first
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Rh[half][par][t + sh], bl[cu][n], acc[t][n], 0, 0, 0);
             }
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cu][t], bh[cu][n], acc[t][n], 0, 0, 0);
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Rh[half][par][t + sh], bh[cu][n], acc[t][n], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);   // keep the next step's reads ahead of this step's MFMAs, per step
-      }
+      });
     }
     stage();   // the next tile's patch (this tile's LDS reads are all consumed)
     // (the constants are first TOUCHED here: without this the scheduler folds the weight pre-scale into the affine right after
