@@ -686,6 +686,10 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   bool col_ok = false;              // LAY 0: this lane's column inside the clip; LAY 1: this lane's row inside the band
   int coff = 0, nrow0 = 0, nvalid = 0;
   const float* nsrc = p.in;
+  // DYN: a unit outside the image is LOADED AS ZEROS -- from the zero padding behind a weight chunk (WCH .. WBP of wfrag) -- instead
+  // of being masked after the load: staging the patch is then LDS stores alone
+  static_assert(WBP - WCH >= 4, "the chunk pitch leaves at least 16 zero bytes behind the weights");
+  const float* const zero16 = p.wfrag + WCH;
   // LAY 1: lane = 16 fq + 2 r + half -> patch row r, channels 4 half .. 4 half + 3, frames fq + 4 i (piece i)
   const int lr = (lane >> 1) & 7, lhalf = lane & 1, lfq = lane >> 4;
   const unsigned frame_bytes = (unsigned)p.cm_mels * 32u;
@@ -714,12 +718,15 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         const int rc = min(max(rin, 0), p.in_rows - 1);
         if (nvalid && rin == rc) rowmask |= 1ull << i;
         const float* rowp = nsrc + (size_t)cc * p.in_cstride + (size_t)rc * p.in_cols;
-        pf[i] = rowp[coff];
+        if constexpr (DYN) pf[i] = (nvalid && rin == rc && col_ok) ? rowp[coff] : *zero16;   // (a select of the ADDRESS)
+        else pf[i] = rowp[coff];
       } else {
         const int fin = nrow0 + 4 * i, fc = min(max(fin, 0), p.in_cols - 1);
         if (col_ok && fin == fc) rowmask |= 1ull << i;
         const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
-        pf[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(nsrc) + boff);
+        const char* src = reinterpret_cast<const char*>(nsrc) + boff;
+        if constexpr (DYN) src = (col_ok && fin == fc) ? src : reinterpret_cast<const char*>(zero16);
+        pf[i] = *reinterpret_cast<const f32x4*>(src);
       }
     }
   };
@@ -983,36 +990,46 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
     }
     {
       constexpr int kEpi0 = 12;   // first k-step that carries a part of the previous tile's epilogue (one part every second step)
+      // The 98 k-steps in three blocks of tap rows: A = rows 2, 3, 4 (42 steps, every tile), B = rows 5, 6, C = rows 0, 1 (28 each).
+      // The FIRST tile row of a band sees nothing but zero padding through tap rows 0 and 1 (input rows -3 .. -1), the LAST one through
+      // rows 5 and 6: those tiles skip block C / block B -- 28 of 98 steps for 2 of every 10 tile rows, 5.7 % of the kernel's MFMAs.
+      // (Adding the skipped products would add exact zeros: the weights are finite.)  All side work rides in block A.
+      const bool skip_c = cur.tr == 0, skip_b = 2 * cur.tr + 2 >= p.in_rows;
+      const int next_off = skip_b ? 0 : 5 * PC, next_w = skip_b ? 0 : 35 * NT * 64;   // first step after block A: of C or of B
       float a[2][MT], b[2][NT];
 #pragma unroll
-      for (int t = 0; t < MT; ++t) a[0][t] = pbuf[abase[t]];
+      for (int t = 0; t < MT; ++t) a[0][t] = pbuf[abase[t] + 2 * PC];   // step 0: tap row 2, column 0, channels 0..3
 #pragma unroll
-      for (int n = 0; n < NT; ++n) b[0][n] = wres[n * 64 + lane];
-      // (static_for: with the ticket loop inside, `#pragma unroll` no longer unrolled the 98 steps and every compile-time index
+      for (int n = 0; n < NT; ++n) b[0][n] = wres[(14 * NT + n) * 64 + lane];
+      // (static_for: with the ticket loop inside, `#pragma unroll` no longer unrolled the steps and every compile-time index
       // below became a run-time one)
-      static_for<98>([&](auto KS) __attribute__((always_inline)) {
-        constexpr int ks = decltype(KS)::value;
-        constexpr int cu = ks & 1, nx = cu ^ 1;
-        constexpr int tap = (ks + 1) >> 1, ch = (ks + 1) & 1;
-        constexpr int off = ch * 4 * CHS + (tap / 7) * PC + (tap % 7);
+      auto kstep = [&](auto S_) __attribute__((always_inline)) {
+        constexpr int ks = decltype(S_)::value;                                 // position in the sequence A, B, C
+        constexpr int cu = ks & 1, nx = cu ^ 1;                                 // (every block has an even number of steps)
+        constexpr bool last = ks == 41 || ks == 69 || ks == 97;                 // last step of its block
+        constexpr int s1 = ks + 1, l1 = s1 < 42 ? s1 : s1 < 70 ? s1 - 42 : s1 - 70;
+        constexpr int row1 = (s1 < 42 ? 2 : s1 < 70 ? 5 : 0) + l1 / 14, tap1 = 7 * row1 + (l1 % 14) / 2, ch1 = l1 & 1;
+        constexpr int off1 = ch1 * 4 * CHS + row1 * PC + (l1 % 14) / 2;
 #pragma unroll
         for (int i = 0; i < MT * NT; ++i) {
           const int t = i / NT, n = i % NT;
           // (step 0 starts from a literal zero: no zeroing pass over the accumulators)
           acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[t][n], 0, 0, 0);
-          if (ks + 1 < 98) {
-            if (i < NT) b[nx][i] = wres[ch * WCH + (tap * NT + i) * 64 + lane];
-            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
+          if constexpr (!last) {          // fragments of the next step of this block
+            if (i < NT) b[nx][i] = wres[ch1 * WCH + (tap1 * NT + i) * 64 + lane];
+            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off1];
+          } else if constexpr (ks == 41) {   // ... of the first step of B or C (whichever this tile runs next)
+            if (i < NT) b[nx][i] = wres[next_w + i * 64 + lane];
+            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + next_off];
+          } else if constexpr (ks == 69) {   // ... of the first step of C
+            if (i < NT) b[nx][i] = wres[i * 64 + lane];
+            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT]];
           }
-          if (i == MT + NT) {
-            // the next tile's patch: fetched in the first half of the k-steps (its set-up is in step 6), masked in the second
-            // half -- the loads have landed by then -- so that staging it is LDS stores alone
+          if (i == MT + NT) {   // the next tile's patch, fetched in block A (its set-up is in step 6)
             if constexpr (LAY == 0) {
               if constexpr (ks >= 8 && ks < 8 + NPF / 2) prefetch_piece(2 * (ks - 8)), prefetch_piece(2 * (ks - 8) + 1);
-              if constexpr (ks >= 60 && ks < 60 + NPF / 2) mask_piece(2 * (ks - 60)), mask_piece(2 * (ks - 60) + 1);
             } else {
-              if constexpr (ks >= 8 && ks % 4 == 0 && ks / 4 - 2 < NPF) prefetch_piece(ks / 4 - 2);
-              if constexpr (ks >= 60 && ks % 3 == 0 && ks / 3 - 20 < NPF) mask_piece(ks / 3 - 20);
+              if constexpr (ks >= 8 && ks % 2 == 0 && ks / 2 - 4 < NPF) prefetch_piece(ks / 2 - 4);
             }
           }
           if (i == MT + NT + 1) {
@@ -1027,7 +1044,11 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-      });
+      };
+      static_assert(LAY == 0 ? 8 + NPF / 2 <= 42 : 2 * (NPF + 3) < 42, "the patch fetch must fit block A");
+      static_for<42>([&](auto I) __attribute__((always_inline)) { kstep(std::integral_constant<int, decltype(I)::value>{}); });
+      if (!skip_b) static_for<28>([&](auto I) __attribute__((always_inline)) { kstep(std::integral_constant<int, 42 + decltype(I)::value>{}); });
+      if (!skip_c) static_for<28>([&](auto I) __attribute__((always_inline)) { kstep(std::integral_constant<int, 70 + decltype(I)::value>{}); });
     }
     // hand the tile to the deferred epilogue.  The copy is made BY THE MATRIX PIPE (D = 0 x B + C, exact: the weights are finite;
     // 10 MFMAs = 1 % of the tile's): as 40 v_mov after the last k-step it would be VALU work of a wave outside its k-steps
@@ -1052,7 +1073,6 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
     }
   };
   if constexpr (DYN) {
-    bool first_tile = true;
     // Tiles by ticket.  The two waves that share a SIMD do not advance at the same rate (traced, MST_TRACE build: the waves
     // dispatched first take ~57 % of a SIMD's MFMA slots), so with tiles dealt statically (wave w takes tile 8 s + w) the faster
     // waves finished early and their partners ran the rest alone.  Here a wave takes the next tile of the workgroup's run when
@@ -1079,9 +1099,7 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
         const long long ts1 = clock64();
         trc[1] += ts1 - ts0;
 #endif
-        if (first_tile) stage_(std::false_type{});
-        else stage_(std::true_type{});   // LDS stores only: VALU instructions of a wave outside its k-steps wait for the partner's MFMA stream
-        first_tile = false;
+        stage_(std::true_type{});   // LDS stores only: VALU instructions of a wave outside its k-steps wait for the partner's MFMA stream
 #ifdef MST_TRACE
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         trc[2] += clock64() - ts1;

@@ -335,7 +335,11 @@ def test_conv_f16x3_is_range_safe_for_any_activation_magnitude(gain):
     parity.record(f"f16x3-all vs fp32 kernels, conv1 gain {gain:g}: embedding", e16, e32)
     d_pin = (t16["pool_in"] - t32["pool_in"]).abs().max().item() / t32["pool_in"].abs().max().item()
     d_emb = (e16 - e32).abs().max().item() / e32.abs().max().item()
-    assert d_pin < 1e-5 and d_emb < 1e-5, (d_pin, d_emb)
+    # pool_in (the convolutions' own output) holds 1e-5 at every gain.  The embedding lies behind the attention softmax, whose logits
+    # scale with the gain: at 3e3 and beyond the frame weights are nearly one-hot and two fp32 summation orders of the SAME
+    # convolution (1e-6 apart in pool_in) already sit ~1e-5 apart there -- observed 0.9e-5 .. 1.2e-5 between builds that differ
+    # only in the order of the taps; 3e-5 is that with a margin, not a looser convolution bound.
+    assert d_pin < 1e-5 and d_emb < (1e-5 if gain < 3e3 else 3e-5), (d_pin, d_emb)
 
 
 def test_conv_f16_amp_mode_matches_its_own_definition():
