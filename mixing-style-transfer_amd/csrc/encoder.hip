@@ -317,6 +317,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     return t;
   };
 
+  // TS (conv2, eval): M-tile t holds tile rows 2 t and 2 t + 1 (lane groups 0, 1 / 2, 3) instead of rows t and t + 4.  The plane's
+  // first tile row then has an M-tile (t = 0: rows 0, 1) that sees NOTHING BUT ZERO PADDING through tap rows 0 and 1 (input rows -3
+  // .. -1): its 4 x 14 MFMAs per chunk are left out -- 56 of 784, 7 % of the kernel, for every tile when the pooled plane is one
+  // tile row high (the contract geometry).  A 4 x 4 pooling window is then spread over the lane pair (l, l ^ 32): one cross-lane
+  // max per output.  The raw-output modes keep the accumulator order their consumers index.
+  constexpr bool TS = LAYER == 2 && MODE == 0;
   // A-fragment base offsets (floats, inside the wave patch) for this lane: row i = lane & 15 of M-tile t maps to
   // accumulator slot e = 4 t + (i & 3) of lane group g = i >> 2, i.e. window e / WIN, position e % WIN.
   const int kq = lane >> 4, ai = lane & 15, ag = ai >> 2, areg = ai & 3;
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
       dr = pos / 5;
       wc = 5 * (C::WPG * ag + wv) + pos % 5;
     } else {
-      dr = 4 * (ag >> 1) + t;
+      dr = TS ? 2 * t + (ag >> 1) : 4 * (ag >> 1) + t;
       wc = 4 * (ag & 1) + areg;
     }
     abase[t] = kq * (PR * PC) + dr * PC + wc;
@@ -449,25 +455,39 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
       for (int t = 0; t < MT; ++t) a[0][t] = pbuf[abase[t]];
 #pragma unroll
       for (int n = 0; n < NT; ++n) b[0][n] = wb[n * 64 + lane];
+      auto taps = [&](auto LO_, auto HI_, auto SKIP_) __attribute__((always_inline)) {
+        constexpr int LO = decltype(LO_)::value, HI = decltype(HI_)::value;
+        constexpr bool SKIP0 = decltype(SKIP_)::value;   // M-tile 0 multiplies zeros in these taps: no MFMAs for it
 #pragma unroll
-      for (int tap = 0; tap < 49; ++tap) {
-        const int cu = tap & 1, nx = cu ^ 1;
-        const int off = ((tap + 1) / 7) * PC + ((tap + 1) % 7);
-        // hand-interleaved issue order, pinned by sched_barrier: after every MFMA one LDS read of the next tap's
-        // fragments (or a global prefetch load of the next chunk) is issued into the shadow of that MFMA
+        for (int tap = LO; tap < HI; ++tap) {
+          const int cu = tap & 1, nx = cu ^ 1;
+          const int off = ((tap + 1) / 7) * PC + ((tap + 1) % 7);
+          // hand-interleaved issue order, pinned by sched_barrier: after every MFMA one LDS read of the next tap's
+          // fragments (or a global prefetch load of the next chunk) is issued into the shadow of that MFMA
 #pragma unroll
-        for (int i = 0; i < MT * NT; ++i) {
-          const int t = i / NT, n = i % NT;
-          // (no per-MFMA skipping of M-tiles past the plane: a wave-uniform branch here cost the training forward half its
-          // speed; the last rows of a 10-row plane go through the strip kernel, MODE 3, and otherwise padding rows are computed)
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
-          if (tap + 1 < 49) {
-            if (i < NT) b[nx][i] = wb[((tap + 1) * NT + i) * 64 + lane];   // B first: needed by the next tap's MFMA 0
-            else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
+          for (int i = 0; i < MT * NT; ++i) {
+            const int t = i / NT, n = i % NT;
+            // (no per-MFMA skipping of M-tiles past the plane: a wave-uniform branch here cost the training forward half its
+            // speed; the last rows of a 10-row plane go through the strip kernel, MODE 3, and otherwise padding rows are computed)
+            if (!(SKIP0 && t == 0)) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][t], b[cu][n], acc[t][n], 0, 0, 0);
+            if (tap + 1 < 49) {
+              if (i < NT) b[nx][i] = wb[((tap + 1) * NT + i) * 64 + lane];   // B first: needed by the next tap's MFMA 0
+              else if (i < MT + NT) a[nx][i - NT] = pbuf[abase[i - NT] + off];
+            }
+            if (i >= MT + NT && i - (MT + NT) < PPT) prefetch_piece(tap * PPT + (i - (MT + NT)));
+            __builtin_amdgcn_sched_barrier(0);
           }
-          if (i >= MT + NT && i - (MT + NT) < PPT) prefetch_piece(tap * PPT + (i - (MT + NT)));
-          __builtin_amdgcn_sched_barrier(0);
         }
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I14 = std::integral_constant<int, 14>;
+      using I49 = std::integral_constant<int, 49>;
+      if constexpr (TS) {   // tap rows 0 and 1 (taps 0 .. 13), with or without M-tile 0; then the rest
+        if (cur.tr == 0) taps(I0{}, I14{}, std::true_type{});
+        else taps(I0{}, I14{}, std::false_type{});
+        taps(I14{}, I49{}, std::false_type{});
+      } else {
+        taps(I0{}, I49{}, std::false_type{});
       }
     }
 #ifdef MST_TRACE
@@ -576,10 +596,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
           }
         } else {
           float m = 0.f;
+          if constexpr (TS) {   // rows 2 t + (g >> 1): pooled row 0 = M-tiles 0, 1 of the lane pair (l, l ^ 32), pooled row 1 = M-tiles 2, 3
+            float m0 = 0.f, m1 = 0.f;
 #pragma unroll
-          for (int t = 0; t < MT; ++t)
+            for (int r = 0; r < 4; ++r) {
+              m0 = fmaxf(m0, fmaxf(fmaf(acc[0][n][r], ac.x, ac.y), fmaf(acc[1][n][r], ac.x, ac.y)));
+              m1 = fmaxf(m1, fmaxf(fmaf(acc[2][n][r], ac.x, ac.y), fmaf(acc[3][n][r], ac.x, ac.y)));
+            }
+            m0 = fmaxf(m0, __shfl_xor(m0, 32, 64));
+            m1 = fmaxf(m1, __shfl_xor(m1, 32, 64));
+            m = (g >> 1) ? m1 : m0;
+          } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaf(acc[t][n][r], ac.x, ac.y));
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) m = fmaxf(m, fmaf(acc[t][n][r], ac.x, ac.y));
+          }
           const int pr = 2 * cur.tr + (g >> 1), pc = 2 * cur.tc + (g & 1);
           if (pr < p.out_rows && pc < p.out_cols)  // pool_in[clip][(band*64 + ch)*FD + pr][pc]
             p.out[(((size_t)cur.clip * p.nsub + cur.band) * C::COUT + ch) * p.out_rows * p.out_cols +
