@@ -135,6 +135,35 @@ def test_batch_independence_and_ragged_tail():
     close(e5, oenc.encoder_from_logmel(sd, lm.cpu(), feats))
 
 
+def test_conv1_set_orders_and_ticketed_tiles_give_the_same_bits(monkeypatch):
+    """conv1's eval forward hands its tiles to whichever wave asks next, inside segments whose extent depends on the order of the
+    sets (`MST_CONV1_CLIP_GROUP`, `MST_CONV1_BAND_MAJOR`, read per launch): every order -- segments of one clip, of three, of the
+    whole batch; a grid with more workgroups than sets (B = 1) -- must return the default order's embeddings bit for bit, in the
+    channel-minor and in the reference log-mel layout."""
+    from mst_amd import _lib
+    model, _ = build_model(cases.CFG_DEFAULT)
+    T = 256 * 260 + 5
+    x = torch.stack([cases.synth_clip(c % 4, T) * (1.0 + 0.05 * c) for c in range(7)], 0).cuda()
+    stems = omel.tensor_to_stems_dict(x)
+    feats = torch.randn(7, 64, generator=torch.Generator().manual_seed(5)).cuda()
+    plan = model.audio_encoder.mel_preprocessor.plan(0)
+    enc = model.hip_encoder()
+    with torch.no_grad():
+        lm_ref = model.audio_encoder.mel_preprocessor(stems)
+        lm_cm, _ = plan.forward_stems(stems, True, False, _lib.LOGMEL_CM32)
+        for lm in (lm_cm, lm_ref):
+            base = enc.forward(lm, feats).clone()
+            for env in ({"MST_CONV1_CLIP_GROUP": "3"}, {"MST_CONV1_CLIP_GROUP": "7"}, {"MST_CONV1_BAND_MAJOR": "1"}):
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                got = enc.forward(lm, feats).clone()
+                for k in env:
+                    monkeypatch.delenv(k)
+                assert torch.equal(got, base), env
+        one = enc.forward(lm_ref[2:3].contiguous(), feats[2:3])
+        assert torch.equal(one[0], enc.forward(lm_ref, feats)[2])
+
+
 def test_torch_backend_agrees_and_train_mode_guard():
     model, _ = build_model(cases.CFG_DEFAULT)
     x = torch.stack([cases.synth_clip(c, 66150) for c in (0, 1)], 0).cuda()
