@@ -2104,52 +2104,83 @@ struct AttnParams {
   int B, C, W, A;
 };
 
+#ifndef MST_ATTN_MT
+#define MST_ATTN_MT 1
+#endif
+#ifndef MST_ATTN_U
+#define MST_ATTN_U 2
+#endif
+constexpr int kAttnMT = MST_ATTN_MT;   // M-tiles (16 frames each) per workgroup: every weight fragment fetched from L2 feeds kAttnMT MFMAs
 __global__ __launch_bounds__(256) void attn_scores_kernel(const AttnParams p) {
-  __shared__ float part_s[4][16];
+  __shared__ float part_s[4][16 * kAttnMT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mt = blockIdx.x;
   const int M = p.B * p.W;
   const int kq = lane >> 4, i = lane & 15;
-  const int m = mt * 16 + i;
-  const bool ok = m < M;
-  const int b = ok ? m / p.W : 0, t = ok ? m % p.W : 0;
-  const float* xa = p.x + ((size_t)b * p.C + kq) * p.W + t;
-  f32x4 acc[4];
+  const float* xa[kAttnMT];
+  bool ok[kAttnMT];
 #pragma unroll
-  for (int n = 0; n < 4; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < kAttnMT; ++q) {
+    const int m = (mt * kAttnMT + q) * 16 + i;
+    ok[q] = m < M;
+    const int b = ok[q] ? m / p.W : 0, t = ok[q] ? m % p.W : 0;
+    xa[q] = p.x + ((size_t)b * p.C + kq) * p.W + t;
+  }
+  f32x4 acc[kAttnMT][4];
+#pragma unroll
+  for (int q = 0; q < kAttnMT; ++q)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[q][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int steps = p.C / 4;
   const float* wf = p.w1frag + (size_t)(wave * 4) * 64 + lane;
-  // 4 k-steps of loads in flight (20 independent loads) before their 16 MFMAs: the loop is latency-bound otherwise
-  for (int sb = 0; sb < steps; sb += 4) {
-    float a[4], bb[4][4];
+  // software-pipelined over batches of kAttnU k-steps: the loads of batch j + 1 are in flight while the MFMAs of batch j run
+  // (the loop is load-latency-bound: one wave per SIMD and a half, 352 dependent-free k-steps)
+  constexpr int kAttnU = MST_ATTN_U;
+  float a[2][kAttnU][kAttnMT], bb[2][kAttnU][4];
+  auto load_batch = [&](int sb, int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < kAttnU; ++u) {
       const int s = min(sb + u, steps - 1);
-      a[u] = (ok && sb + u < steps) ? xa[(size_t)s * 4 * p.W] : 0.f;   // a zero A fragment makes a padded step a no-op
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bb[u][n] = wf[((size_t)s * 16 + n) * 64];
+      for (int q = 0; q < kAttnMT; ++q)
+        a[buf][u][q] = (ok[q] && sb + u < steps) ? xa[q][(size_t)s * 4 * p.W] : 0.f;   // a zero A fragment makes a padded step a no-op
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bb[buf][u][n] = wf[((size_t)s * 16 + n) * 64];
     }
+  };
+  auto mfma_batch = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < kAttnU; ++u)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bb[u][n], acc[n], 0, 0, 0);
+      for (int q = 0; q < kAttnMT; ++q)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[q][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][u][q], bb[buf][u][n], acc[q][n], 0, 0, 0);
+  };
+  load_batch(0, 0);
+  for (int sb = 0; sb < steps; sb += 2 * kAttnU) {   // (a batch past the end loads clamped addresses and multiplies zeros)
+    load_batch(sb + kAttnU, 1);
+    mfma_batch(0);
+    load_batch(sb + 2 * kAttnU, 0);
+    mfma_batch(1);
   }
-  // rows 4*kq + r of this M-tile live in lane group kq; columns (wave*4 + n)*16 + i
+  // rows 4*kq + r of an M-tile live in lane group kq; columns (wave*4 + n)*16 + i
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float part = 0.f;
+  for (int q = 0; q < kAttnMT; ++q)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int h = (wave * 4 + n) * 16 + i;
-      part = fmaf(p.w2[h], tanhf(acc[n][r] + p.b1[h]), part);
+    for (int r = 0; r < 4; ++r) {
+      float part = 0.f;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int h = (wave * 4 + n) * 16 + i;
+        part = fmaf(p.w2[h], tanhf(acc[q][n][r] + p.b1[h]), part);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+      if (i == 0) part_s[wave][16 * q + 4 * kq + r] = part;
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    if (i == 0) part_s[wave][4 * kq + r] = part;
-  }
   __syncthreads();
-  if (threadIdx.x < 16) {
-    const int mr = mt * 16 + threadIdx.x;
+  if (threadIdx.x < 16 * kAttnMT) {
+    const int mr = mt * 16 * kAttnMT + threadIdx.x;
     if (mr < M)
       p.scores[mr] = ((part_s[0][threadIdx.x] + part_s[1][threadIdx.x]) + (part_s[2][threadIdx.x] + part_s[3][threadIdx.x])) + p.b2[0];
   }
@@ -3818,7 +3849,7 @@ int mst_encoder_forward_in(const mst_encoder* e, const mst_logmel_in* lin, int f
   mark(3);
   {
     AttnParams ap{pool_in, e->att0frag, e->att0_b, e->att2_w, e->att2_b, scores, B, e->C, L.W2, e->cfg.attn_hidden};
-    const int mtiles = (B * L.W2 + 15) / 16;
+    const int mtiles = (B * L.W2 + 16 * kAttnMT - 1) / (16 * kAttnMT);
     hipLaunchKernelGGL(attn_scores_kernel, dim3(mtiles), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
   }
@@ -4186,7 +4217,7 @@ int mst_encoder_forward_train_in(const mst_encoder* e, const mst_logmel_in* lin,
   }
   if (emb) {   // attention pooling head (emb == NULL: the caller runs its own head on pool_in)
     AttnParams ap{pool_in, e->att0frag, e->att0_b, e->att2_w, e->att2_b, scores, B, e->C, L.W2, e->cfg.attn_hidden};
-    const int mtiles = (B * L.W2 + 15) / 16;
+    const int mtiles = (B * L.W2 + 16 * kAttnMT - 1) / (16 * kAttnMT);
     hipLaunchKernelGGL(attn_scores_kernel, dim3(mtiles), dim3(256), 0, st, ap);
     MST_HIP_CHECK(hipGetLastError());
     float* pooled = reinterpret_cast<float*>(ws + L.pooled);

@@ -30,5 +30,6 @@ def run(n):
 run(3)
 evs = run(12)
 c1 = sorted(e[1].elapsed_time(e[2]) for e in evs); c2 = sorted(e[2].elapsed_time(e[3]) for e in evs)
+at = sorted(e[3].elapsed_time(e[4]) for e in evs); pp = sorted(e[4].elapsed_time(e[5]) for e in evs); fm = sorted(e[0].elapsed_time(e[1]) for e in evs)
 tag = " ".join(f"{k}={v}" for k, v in sorted(os.environ.items()) if k.startswith("MST_"))
-print(f"{prec:10s} {tag:40s} conv1 median {c1[6]:.4f} min {c1[0]:.4f}   conv2 median {c2[6]:.4f} min {c2[0]:.4f}", flush=True)
+print(f"{prec:10s} {tag:40s} conv1 median {c1[6]:.4f} min {c1[0]:.4f}   conv2 median {c2[6]:.4f} min {c2[0]:.4f}   film {fm[6]:.4f} attn {at[6]:.4f} pool+proj {pp[6]:.4f}", flush=True)
