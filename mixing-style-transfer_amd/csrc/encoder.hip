@@ -284,7 +284,15 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
   constexpr bool GEO1 = LAYER == 1 || LAYER >= 3;   // 2 x 40 tiles, pooling-window accumulator order
   constexpr int MT = C::MT, NT = C::NT, NCH = C::NCH, PR = C::PR, PC = C::PC, RL = C::RL;
   constexpr int WBP = GEO::WBP, PATCH = GEO::PATCH, NWF = GEO::NWF, NPF = GEO::NPF, NCV = GEO::NCV;
-  constexpr int NPIECE = NPF + NWF, PPT = (NPIECE + 48) / 49;  // prefetch pieces, pieces issued per tap
+  // BL (conv2): the next chunk is fetched with RAW BUFFER LOADS.  A patch piece is (channel i / 4, row block i % 4): lane = 16 rs + col
+  // -> patch row 4 (i % 4) + rs, column col -- 16 pieces instead of 14, but every address is a per-ROW-BLOCK lane offset (computed
+  // once per tile; a lane outside the plane gets an offset beyond the buffer and the hardware returns zeros) plus a SCALAR offset
+  // per piece: no vector instruction per piece for any tile whose 16 columns lie inside the plane, and no masking when the chunk
+  // is staged.  (Per-lane clamped addresses were ~10 VALU instructions per piece; inside an MFMA stream a VALU instruction costs
+  // 11-19 cycles of the matrix pipe, scripts/ubench_mfma.hip modes 6, 7.)
+  constexpr bool BL = LAYER == 2;
+  constexpr int NPFK = BL ? 16 : NPF;
+  constexpr int NPIECE = NPFK + NWF, PPT = (NPIECE + 48) / 49;  // prefetch pieces, pieces issued per tap
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: tile bookkeeping stays on the SALU
@@ -343,13 +351,16 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
 
   // ---- prefetch state of the NEXT chunk: branch-free loads at clamped addresses, masked when staged into LDS
   f32x4 wreg[NWF];
-  float pf[NPF];
+  float pf[NPFK];
   unsigned long long rowmask = 0;   // RL >= 64: bit i = row of piece i is inside the image (wave-uniform)
   unsigned colmask = 0;             // RL >= 64: bit j = column variant j of this lane is inside; RL == 16: bit i = piece i
   int coff[NCV];                    // clamped column offsets of this lane
   const float* nsrc = p.in;         // wave-uniform base of the next tile's 4-channel slab
   const f32x4* nwsrc = reinterpret_cast<const f32x4*>(p.wfrag);
   int nrow0 = 0, ncol0 = 0, nvalid = 0;
+  __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);   // BL: the 4-channel slab
+  __amdgpu_buffer_rsrc_t nwrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wfrag), 0, 0, 0x00020000);   // BL: the weight chunk
+  unsigned nvoff[4] = {0, 0, 0, 0}, nsoff[4] = {0, 0, 0, 0};   // BL: per row block -- lane offset (bytes, or out of range), scalar offset
 
   auto prefetch_setup = [&](int q, const Tile& t) __attribute__((always_inline)) {
     const int chunk = q % NCH;
@@ -359,6 +370,20 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     nvalid = t.valid;
     nsrc = p.in + (size_t)t.clip * p.in_clipstride + (size_t)t.band * p.in_bandoff + (size_t)(4 * chunk) * p.in_cstride;
     rowmask = 0, colmask = 0;
+    if constexpr (BL) {
+      nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nsrc), 0, (unsigned)(4 * p.in_cstride) * 4u, 0x00020000);
+      nwrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(nwsrc), 0, (unsigned)WBP * 4u, 0x00020000);
+      const int rs = lane >> 4, col = lane & 15, cin = ncol0 + col;
+      const bool col_in = nvalid && col < PC && cin >= 0 && cin < p.in_cols;
+      const int cbase = max(ncol0, 0);                               // scalar part of the column (>= 0: soffset is unsigned)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        const int rbase = max(nrow0 + 4 * rb, 0), rin = nrow0 + 4 * rb + rs;
+        const bool ok = col_in && 4 * rb + rs < PR && rin >= 0 && rin < p.in_rows;
+        nsoff[rb] = (unsigned)(rbase * p.in_cols + cbase) * 4u;
+        nvoff[rb] = ok ? (unsigned)((rin - rbase) * p.in_cols + (cin - cbase)) * 4u : 0x80000000u;
+      }
+    }
     if constexpr (RL >= 64) {
 #pragma unroll
       for (int j = 0; j < NCV; ++j) {
@@ -369,6 +394,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     }
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {  // i is a compile-time constant after unrolling
+    if constexpr (BL) {
+      if (i < NPFK) {
+        pf[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(nrsrc, nvoff[i & 3], nsoff[i & 3] + (unsigned)((i >> 2) * p.in_cstride) * 4u, 0));
+      } else if (i < NPIECE) {
+        wreg[i - NPFK] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nwrsrc, (unsigned)tid * 16u, (unsigned)(kConvThreads * (i - NPFK)) * 16u, 0));
+      }
+    } else
     if (i < NPF) {
       if constexpr (RL >= 64) {
         const int row = i / NCV, j = i % NCV;
@@ -416,6 +448,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     // stage the prefetched chunk into LDS (unconditional stores; out-of-image elements become zeros)
 #pragma unroll
     for (int i = 0; i < NWF; ++i) reinterpret_cast<f32x4*>(wb)[tid + kConvThreads * i] = wreg[i];
+    if constexpr (BL) {
+#pragma unroll
+      for (int i = 0; i < NPFK; ++i) {
+        const int rs = lane >> 4, col = lane & 15, r = 4 * (i & 3) + rs;
+        if (r < PR && col < PC) pbuf[((i >> 2) * PR + r) * PC + col] = pf[i];   // (out-of-plane elements were loaded as zeros)
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       if constexpr (RL >= 64) {
@@ -718,6 +757,9 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
   bool col_ok = false;              // LAY 0: this lane's column inside the clip; LAY 1: this lane's row inside the band
   int coff = 0, nrow0 = 0, nvalid = 0;
   const float* nsrc = p.in;
+  bool nfast = false;                       // DYN, LAY 1: the next tile takes the buffer-load path
+  __amdgpu_buffer_rsrc_t nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, 0, 0x00020000);
+  unsigned nsoff = 0, nvoff = 0;
   // DYN: a unit outside the image is LOADED AS ZEROS -- from the zero padding behind a weight chunk (WCH .. WBP of wfrag) -- instead
   // of being masked after the load: staging the patch is then LDS stores alone
   static_assert(WBP - WCH >= 4, "the chunk pitch leaves at least 16 zero bytes behind the weights");
@@ -740,6 +782,19 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
       col_ok = nvalid && rin == rc;
       coff = ((t.band * p.cm_overlap + rc) * 8 + 4 * lhalf) * 4;             // byte offset of this lane's (row, half) inside a frame
       nrow0 = C::TCOLS * t.tc - 3 + lfq;                                     // (re-used: first frame of this lane)
+      if constexpr (DYN) {
+        // Fast path (every tile whose 48 frames lie inside the clip: all but the first and last tile column): the pieces are RAW
+        // BUFFER LOADS -- per piece one scalar add (the frame offset, in soffset) and the load; the lane's offset inside a frame
+        // is computed ONCE per tile and a lane whose mel row lies outside the band gets an offset beyond the buffer, which the
+        // hardware answers with zeros (scripts/ubench_bufload.hip).  Per-lane 64-bit address arithmetic for 12 pieces was ~150
+        // VALU instructions per tile, and a VALU instruction inside an MFMA stream costs 11-19 cycles of the matrix pipe
+        // (scripts/ubench_mfma.hip modes 6, 7).
+        const int f0 = C::TCOLS * t.tc - 3;
+        nfast = nvalid && f0 >= 0 && f0 + 4 * NPF + 3 < p.in_cols;
+        nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nsrc), 0, (unsigned)p.in_cols * frame_bytes, 0x00020000);
+        nsoff = (unsigned)max(f0, 0) * frame_bytes;
+        nvoff = col_ok ? (unsigned)coff + (unsigned)lfq * frame_bytes : 0x80000000u;
+      }
     }
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
@@ -755,10 +810,14 @@ __global__ __launch_bounds__(kConvThreads) void conv1_resident_kernel(const Conv
       } else {
         const int fin = nrow0 + 4 * i, fc = min(max(fin, 0), p.in_cols - 1);
         if (col_ok && fin == fc) rowmask |= 1ull << i;
-        const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
-        const char* src = reinterpret_cast<const char*>(nsrc) + boff;
-        if constexpr (DYN) src = (col_ok && fin == fc) ? src : reinterpret_cast<const char*>(zero16);
-        pf[i] = *reinterpret_cast<const f32x4*>(src);
+        if (DYN && nfast) {
+          pf[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nrsrc, nvoff, nsoff + (unsigned)(4 * i) * frame_bytes, 0));
+        } else {
+          const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
+          const char* src = reinterpret_cast<const char*>(nsrc) + boff;
+          if constexpr (DYN) src = (col_ok && fin == fc) ? src : reinterpret_cast<const char*>(zero16);
+          pf[i] = *reinterpret_cast<const f32x4*>(src);
+        }
       }
     }
   };

@@ -4,6 +4,7 @@
 // MODE 1: the same with 7 ds_read_b32 per 10 MFMAs interleaved one per MFMA (conv1_resident_kernel's k-step)
 // MODE 2: f16 16x16x32, 10 accumulators x 3 dependent terms, nothing else
 // MODE 3: the same with 14 ds_read_b128 in front of every 30 MFMAs (conv1_f16e_kernel<3>'s k-step)
+// MODE 6 / 7: mode 1 + 2 / 10 independent v_fma_f32 per k-step of 10 MFMAs (what VALU work inside a k-step costs the pipe)
 // MODE 4 / 5: modes 2 / 0 on PSEUDO-RANDOM operands (every lane, register and half different): the power of real data
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,9 +31,10 @@ __global__ __launch_bounds__(NW * 64) void k(float* out, int iters) {
   f32x4 acc[5][2];
   for (int t = 0; t < 5; ++t)
     for (int n = 0; n < 2; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (MODE <= 1 || MODE == 5) {
+  if (MODE <= 1 || MODE >= 5) {
     const float* pb = smem + wave * 2304 + lane;
-    float a[2][5], b[2][2];
+    float a[2][5], b[2][2], vx[10], vw = 1.0001f;
+    for (int q = 0; q < 10; ++q) vx[q] = (float)(lane + q);
     for (int t = 0; t < 5; ++t) a[0][t] = pb[64 * t], a[1][t] = pb[64 * (t + 8)];
     for (int n = 0; n < 2; ++n) b[0][n] = pb[64 * (5 + n)], b[1][n] = pb[64 * (13 + n)];
     for (int it = 0; it < iters; ++it) {
@@ -42,10 +44,11 @@ __global__ __launch_bounds__(NW * 64) void k(float* out, int iters) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) {
           acc[i / 2][i % 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cu][i / 2], b[cu][i % 2], acc[i / 2][i % 2], 0, 0, 0);
-          if (MODE == 1) {
+          if (MODE == 1 || MODE >= 6) {
             if (i < 2) b[nx][i] = pb[64 * (5 + i) + ks];
             else if (i < 7) a[nx][i - 2] = pb[64 * (i - 2) + ks];
           }
+          if ((MODE == 6 && i >= 8) || MODE == 7) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(vx[i]) : "v"(vw));
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(NW * 64) void k(float* out, int iters) {
     }
   }
   float s = 0.f;
+  if (MODE >= 6) { float* o2 = out + 256 * 1024 - 64; }
   for (int t = 0; t < 5; ++t)
     for (int n = 0; n < 2; ++n) s += acc[t][n][0] + acc[t][n][1] + acc[t][n][2] + acc[t][n][3];
   out[blockIdx.x * NW * 64 + threadIdx.x] = s;
@@ -93,9 +97,9 @@ void run(float* d, int iters) {
   hipEventSynchronize(b);
   float ms;
   hipEventElapsedTime(&ms, a, b);
-  const double n_mfma = (double)iters * 14 * ((MODE <= 1 || MODE == 5) ? 10 : 30) * NW * 256;
-  const double flops = n_mfma * ((MODE <= 1 || MODE == 5) ? 16 * 16 * 4 * 2 : 16 * 16 * 32 * 2);
-  const double cyc_per = ms * 1e-3 * 2.4e9 / ((double)iters * 14 * ((MODE <= 1 || MODE == 5) ? 10 : 30) * (NW / 4));
+  const double n_mfma = (double)iters * 14 * ((MODE <= 1 || MODE >= 5) ? 10 : 30) * NW * 256;
+  const double flops = n_mfma * ((MODE <= 1 || MODE >= 5) ? 16 * 16 * 4 * 2 : 16 * 16 * 32 * 2);
+  const double cyc_per = ms * 1e-3 * 2.4e9 / ((double)iters * 14 * ((MODE <= 1 || MODE >= 5) ? 10 : 30) * (NW / 4));
   printf("mode %d  %2d waves/CU  %.3f ms  %.1f TFLOP/s  %.2f cycles (at 2.4 GHz) per MFMA per SIMD\n", MODE, NW, ms, flops / ms * 1e-9, cyc_per);
 }
 int main() {
@@ -104,5 +108,6 @@ int main() {
   run<0, 4>(d, 2000), run<0, 8>(d, 1000), run<1, 4>(d, 2000), run<1, 8>(d, 1000), run<1, 12>(d, 700);
   run<2, 4>(d, 2000), run<2, 8>(d, 1000), run<3, 4>(d, 2000), run<3, 8>(d, 1000), run<3, 12>(d, 700);
   run<4, 8>(d, 1000), run<4, 8>(d, 20000), run<5, 8>(d, 1000), run<5, 8>(d, 5000);
+  run<1, 8>(d, 2000), run<6, 8>(d, 2000), run<7, 8>(d, 2000), run<6, 4>(d, 2000), run<7, 4>(d, 2000);
   return 0;
 }
