@@ -1710,8 +1710,15 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
   const int base1 = ((q1 >> 1) + 2) * kF16eRS + (q1 & 1) * kF16eOdd + 10 * ag + adc;                 // odd steps (tap rows 4..6, 6)
 
   h16x8 pf[NPF], pfl[TERMS == 3 ? NPF : 1];
-  unsigned rowmask = 0;
   bool row_ok = false;
+  // The pieces are RAW BUFFER LOADS: a lane whose mel row (or, in the first / last tile column, frame) lies outside the image gets an
+  // offset beyond the buffer and reads zeros -- no masks when the patch is staged -- and for every other tile column a piece is one
+  // scalar add and the load (lane offset once per tile).  Vector instructions inside an MFMA stream are not free
+  // (scripts/ubench_mfma.hip modes 6, 7).
+  bool nfast = false;
+  __amdgpu_buffer_rsrc_t nrs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(static_cast<const void*>(p.in))), 0, 0, 0x00020000);
+  __amdgpu_buffer_rsrc_t nrs_lo = nrs_hi;
+  unsigned nvoff = 0, nsoff = 0;
   int coff = 0, frame0 = 0, nvalid = 0;
   const char* nsrc = static_cast<const char*>(static_cast<const void*>(p.in));
   const char* nsrc_lo = static_cast<const char*>(p.in_lo);
@@ -1722,21 +1729,29 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
   auto prefetch_setup = [&](const Tile& t) __attribute__((always_inline)) {
     const int rin = C::TROWS * t.tr - 3 + lr, rc = min(max(rin, 0), p.in_rows - 1);
     nvalid = t.valid;
-    rowmask = 0;
     const size_t cb = (size_t)t.clip * p.in_clipstride * 2;                 // bytes: in_clipstride counts float16 elements
     nsrc = static_cast<const char*>(static_cast<const void*>(p.in)) + cb;   // wave-uniform clip base (high parts)
     nsrc_lo = static_cast<const char*>(p.in_lo) + cb;
     row_ok = nvalid && rin == rc;
     coff = (t.band * p.cm_overlap + rc) * 16;
     frame0 = C::TCOLS * t.tc - 3 + lfq;
+    const int f0 = C::TCOLS * t.tc - 3;
+    nfast = nvalid && f0 >= 0 && f0 + 8 * NPF <= p.in_cols;
+    nrs_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(nsrc), 0, (unsigned)p.in_cols * frame_bytes, 0x00020000);
+    if (TERMS == 3) nrs_lo = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(nsrc_lo), 0, (unsigned)p.in_cols * frame_bytes, 0x00020000);
+    nsoff = (unsigned)max(f0, 0) * frame_bytes;
+    nvoff = row_ok ? (unsigned)coff + (unsigned)lfq * frame_bytes : 0x80000000u;
   };
   auto prefetch_piece = [&](int i) __attribute__((always_inline)) {
     if (i < NPF) {
-      const int fin = frame0 + 8 * i, fc = min(max(fin, 0), p.in_cols - 1);
-      if (row_ok && fin == fc) rowmask |= 1u << i;
-      const unsigned boff = (unsigned)fc * frame_bytes + (unsigned)coff;   // 32-bit offset from the scalar clip base
-      pf[i] = *reinterpret_cast<const h16x8*>(nsrc + boff);
-      if (TERMS == 3) pfl[i] = *reinterpret_cast<const h16x8*>(nsrc_lo + boff);
+      unsigned vo = nvoff, so = nsoff + (unsigned)(8 * i) * frame_bytes;
+      if (!nfast) {   // first / last tile column (or no tile): per-lane frame validity
+        const int fin = frame0 + 8 * i;
+        vo = (row_ok && fin >= 0 && fin < p.in_cols) ? (unsigned)fin * frame_bytes + (unsigned)coff : 0x80000000u;
+        so = 0;
+      }
+      pf[i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(nrs_hi, vo, so, 0));
+      if (TERMS == 3) pfl[i] = __builtin_bit_cast(h16x8, __builtin_amdgcn_raw_buffer_load_b128(nrs_lo, vo, so, 0));
     }
   };
 
@@ -1749,15 +1764,13 @@ __global__ __launch_bounds__(kF16eWaves<TERMS> * 64) void conv1_f16e_kernel(cons
   for (int i = 0; i < NPF; ++i) prefetch_piece(i);
 
   // stage the prefetched patch: one 16-byte vector per position, rows split into the even and the odd part
-  auto stage = [&]() __attribute__((always_inline)) {
-    const h16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stage = [&]() __attribute__((always_inline)) {   // LDS stores only (units outside the image were loaded as zeros)
     const int wbase = (lr >> 1) * kF16eRS + (lr & 1) * kF16eOdd + lfq;
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
       if (8 * i + 7 < PC || 8 * i + lfq < PC) {
-        const bool ok = (rowmask >> i) & 1u;
-        phi[wbase + 8 * i] = ok ? pf[i] : z;
-        if (TERMS == 3) plo[wbase + 8 * i] = ok ? pfl[i] : z;
+        phi[wbase + 8 * i] = pf[i];
+        if (TERMS == 3) plo[wbase + 8 * i] = pfl[i];
       }
     }
   };
