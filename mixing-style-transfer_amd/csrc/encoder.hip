@@ -40,6 +40,10 @@ struct FilmParams {
   int Fd, H, nsub;
 };
 
+#ifndef MST_FILM_U
+#define MST_FILM_U 4   // iterations of the three dot-product loops in flight (16 loads per thread): the kernel is load-latency-bound
+                     // (71 -> 45 us per 72 clips; 8 and 16 spill: 123 us)
+#endif
 __global__ __launch_bounds__(256) void film_kernel(const FilmParams p) {
   // grid = (clip, group of sub-bands); the two small hidden layers are recomputed per group (82 k MACs)
   extern __shared__ float sm[];
@@ -56,6 +60,7 @@ __global__ __launch_bounds__(256) void film_kernel(const FilmParams p) {
   for (int j = tid; j < p.H; j += 256) {
     float a0 = p.b0[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = 0;
+#pragma unroll MST_FILM_U
     for (; i + 3 < p.Fd; i += 4) {
       a0 = fmaf(p.w0t[(size_t)i * p.H + j], f[i], a0);
       a1 = fmaf(p.w0t[(size_t)(i + 1) * p.H + j], f[i + 1], a1);
@@ -69,6 +74,7 @@ __global__ __launch_bounds__(256) void film_kernel(const FilmParams p) {
   for (int j = tid; j < p.H; j += 256) {
     float a0 = p.b3[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = 0;
+#pragma unroll MST_FILM_U
     for (; i + 3 < p.H; i += 4) {
       a0 = fmaf(p.w3t[(size_t)i * p.H + j], h1[i], a0);
       a1 = fmaf(p.w3t[(size_t)(i + 1) * p.H + j], h1[i + 1], a1);
@@ -84,6 +90,7 @@ __global__ __launch_bounds__(256) void film_kernel(const FilmParams p) {
   for (int o = band0 * 192 + tid; o < band1 * 192; o += 256) {
     float a0 = p.hb[o], a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = 0;
+#pragma unroll MST_FILM_U
     for (; i + 3 < p.H; i += 4) {
       a0 = fmaf(p.hwt[(size_t)i * nout + o], h2[i], a0);
       a1 = fmaf(p.hwt[(size_t)(i + 1) * nout + o], h2[i + 1], a1);
