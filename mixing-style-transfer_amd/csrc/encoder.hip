@@ -380,15 +380,17 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     if constexpr (BL) {
       nrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(nsrc), 0, (unsigned)(4 * p.in_cstride) * 4u, 0x00020000);
       nwrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(nwsrc), 0, (unsigned)WBP * 4u, 0x00020000);
-      const int rs = lane >> 4, col = lane & 15, cin = ncol0 + col;
-      const bool col_in = nvalid && col < PC && cin >= 0 && cin < p.in_cols;
-      const int cbase = max(ncol0, 0);                               // scalar part of the column (>= 0: soffset is unsigned)
+      if (chunk == 0) {   // the lane offsets belong to the TILE: once per NCH chunks (between chunks only the two scalar bases move)
+        const int rs = lane >> 4, col = lane & 15, cin = ncol0 + col;
+        const bool col_in = nvalid && col < PC && cin >= 0 && cin < p.in_cols;
+        const int cbase = max(ncol0, 0);                               // scalar part of the column (>= 0: soffset is unsigned)
 #pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const int rbase = max(nrow0 + 4 * rb, 0), rin = nrow0 + 4 * rb + rs;
-        const bool ok = col_in && 4 * rb + rs < PR && rin >= 0 && rin < p.in_rows;
-        nsoff[rb] = (unsigned)(rbase * p.in_cols + cbase) * 4u;
-        nvoff[rb] = ok ? (unsigned)((rin - rbase) * p.in_cols + (cin - cbase)) * 4u : 0x80000000u;
+        for (int rb = 0; rb < 4; ++rb) {
+          const int rbase = max(nrow0 + 4 * rb, 0), rin = nrow0 + 4 * rb + rs;
+          const bool ok = col_in && 4 * rb + rs < PR && rin >= 0 && rin < p.in_rows;
+          nsoff[rb] = (unsigned)(rbase * p.in_cols + cbase) * 4u;
+          nvoff[rb] = ok ? (unsigned)((rin - rbase) * p.in_cols + (cin - cbase)) * 4u : 0x80000000u;
+        }
       }
     }
     if constexpr (RL >= 64) {
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_kernel(const ConvParams p) 
     trc[0] += tq1 - tq0, trc[1] += tq2 - tq1, trc[4] += 1;
 #endif
     cur = nxt;
-    nxt = decode(q + 1);
+    if (!BL || (q + 1) % NCH == 0) nxt = decode(q + 1);   // (BL: the tile -- three integer divisions -- changes every NCH chunks only)
     prefetch_setup(q + 1, nxt);   // past the end this re-reads valid memory and is never staged
     const int chunk = q % NCH;
     if (chunk == 0) {
